@@ -1,0 +1,239 @@
+"""CPU: the oracle (oracle/) against the golden vectors captured from the reference
+(tests/golden/*.npz, made by tests/golden/make_golden.py).
+
+Same-host property: in the container that generated the fixtures the oracle is
+bit-equal to the reference (checked with EXACT=1).  Elsewhere (other host ISA /
+oneDNN kernel choice / thread count) fp32 results may move in the last bits, so
+the default comparison uses the tolerances below; integer outputs stay exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import unet as OU, diffusion as OD, geometry as OG
+from detweights import det_state_dict, checksum
+
+EXACT = os.environ.get('EXACT', '0') == '1'
+RTOL, ATOL = 2e-4, 2e-5
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = torch.as_tensor(np.asarray(a))
+    b = torch.as_tensor(np.asarray(b))
+    if EXACT:
+        assert torch.equal(a, b), float((a.double() - b.double()).abs().max())
+    else:
+        torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+@pytest.fixture(scope='module')
+def meta(golden_dir):
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        return json.load(f)
+
+
+def load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name + '.npz')).items()}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def sd_from(meta, name, seed=0):
+    shapes = {k: tuple(v) for k, v in meta[name + '_keys'].items()}
+    sd = det_state_dict(shapes, seed)
+    if name + '_checksum' in meta:
+        assert checksum(sd) == pytest.approx(meta[name + '_checksum'], rel=1e-12), \
+            'deterministic weights differ from the ones the fixtures were generated with'
+    return sd
+
+
+# ------------------------------------------------------------------------- F1
+def test_unet_cfg_tiny(golden_dir, meta):
+    g = load(golden_dir, 'unet_cfg_tiny')
+    sd = sd_from(meta, 'unet_cfg_tiny')
+    x, t, c, rf, m = (T(g[k]) for k in ('x', 't', 'classes', 'rgb_flow', 'mask'))
+    taps = {}
+    with torch.no_grad():
+        close(OU.cfg_unet_forward(sd, x, t, c, rf, m, None, taps=taps), g['out_cond'])
+        for k, v in taps.items():
+            if 'tap.' + k in g:
+                close(v, g['tap.' + k])
+        null = torch.zeros(2, dtype=torch.bool)
+        close(OU.cfg_unet_forward(sd, x, t, c, rf, m, null), g['out_null'])
+        close(OU.cfg_unet_forward(sd, x, t, c, rf, m, T(g['keep_half'])), g['out_half'])
+        close(OU.cfg_unet_forward_with_cond_scale(sd, x, t, c, rf, m, T(g['keep_scale3']), 3.),
+              g['out_scale3'], atol=1e-4)
+
+
+# ------------------------------------------------------------------------- F2
+@pytest.mark.parametrize('tag', ['nosc', 'sc'])
+def test_unet_ddp_tiny(golden_dir, meta, tag):
+    g = load(golden_dir, 'unet_ddp_tiny')
+    sd = sd_from(meta, f'unet_ddp_tiny_{tag}', seed=1)
+    x, xs, t = T(g['x']), T(g['x_self_cond']), T(g['t'])
+    with torch.no_grad():
+        if tag == 'sc':
+            close(OU.ddp_unet_forward(sd, x, t, xs, True), g['sc.out'])
+            close(OU.ddp_unet_forward(sd, x, t, None, True), g['sc.out_default'])
+        else:
+            close(OU.ddp_unet_forward(sd, x, t), g['nosc.out'])
+
+
+# ------------------------------------------------------------------------- F3
+def _shapes_block(cin, cout):
+    return {'proj.weight': (cout, cin, 3, 3), 'proj.bias': (cout,), 'norm.weight': (cout,), 'norm.bias': (cout,)}
+
+
+def _shapes_resnet(cin, cout, emb=512):
+    s = {'mlp.1.weight': (2 * cout, emb), 'mlp.1.bias': (2 * cout,)}
+    s.update({'block1.' + k: v for k, v in _shapes_block(cin, cout).items()})
+    s.update({'block2.' + k: v for k, v in _shapes_block(cout, cout).items()})
+    if cin != cout:
+        s.update({'res_conv.weight': (cout, cin, 1, 1), 'res_conv.bias': (cout,)})
+    return s
+
+
+def test_blocks_fullwidth(golden_dir):
+    g = load(golden_dir, 'blocks_fullwidth')
+    xb, xa = T(g['block.x']), T(g['attn.x'])
+    with torch.no_grad():
+        p = det_state_dict(_shapes_block(64, 64), 2)
+        close(OU.block(p, xb, 8, (T(g['block.scale']), T(g['block.shift']))), g['block.out'])
+        close(OU.block(p, xb, 8), g['block.out_noss'])
+        te, ce = T(g['resnet.t']), T(g['resnet.c'])
+        cond = torch.cat((te, ce), -1)
+        close(OU.resnet_block(det_state_dict(_shapes_resnet(128, 64), 3), T(g['resnet.x']), 8, cond), g['resnet.out'])
+        close(OU.resnet_block(det_state_dict(_shapes_resnet(64, 64), 4), xb, 8, cond), g['resnet_id.out'])
+        la = {'fn.norm.g': (1, 64, 1, 1), 'fn.fn.to_qkv.weight': (384, 64, 1, 1),
+              'fn.fn.to_out.0.weight': (64, 128, 1, 1), 'fn.fn.to_out.0.bias': (64,),
+              'fn.fn.to_out.1.g': (1, 64, 1, 1)}
+        close(OU._res_prenorm(det_state_dict(la, 5), xb, OU.linear_attention), g['linattn.out'])
+        at = {'fn.norm.g': (1, 128, 1, 1), 'fn.fn.to_qkv.weight': (384, 128, 1, 1),
+              'fn.fn.to_out.weight': (128, 128, 1, 1), 'fn.fn.to_out.bias': (128,)}
+        close(OU._res_prenorm(det_state_dict(at, 6), xa, OU.attention), g['attn.out'])
+        close(OU._downsample(det_state_dict({'weight': (128, 64, 4, 4), 'bias': (128,)}, 7), xb), g['down.out'])
+        close(OU._upsample(det_state_dict({'1.weight': (64, 128, 3, 3), '1.bias': (64,)}, 8), xa), g['up.out'])
+        close(OU._downsample(det_state_dict({'1.weight': (128, 256, 1, 1), '1.bias': (128,)}, 9), xb), g['down_ddp.out'])
+
+
+# ------------------------------------------------------------------------- F4
+def test_schedule(golden_dir):
+    g = load(golden_dir, 'schedule')
+    for sched, Tn in (('cosine', 1000), ('linear', 1000), ('cosine', 10)):
+        buf = OD.schedule_buffers(Tn, sched)
+        assert set(buf) == set(OD.BUFFER_NAMES)
+        for k, v in buf.items():
+            assert v.dtype == torch.float32
+            assert torch.equal(v, T(g[f'{sched}{Tn}.{k}'])), k
+    for S in (4, 32, 250):
+        pairs = OD.ddim_time_pairs(1000, S)
+        times = [p[0] for p in pairs] + [pairs[-1][1]]
+        assert times == g[f'times{S}'].tolist()
+    assert [p[0] for p in OD.ddim_time_pairs(1000, 4)] == [999, 749, 499, 249]
+
+
+# ------------------------------------------------------------------------- F5
+@pytest.mark.parametrize('obj', ['pred_x0', 'pred_noise', 'pred_v'])
+def test_ddim_trace(golden_dir, meta, obj):
+    g = load(golden_dir, 'ddim_trace')
+    sd = sd_from(meta, 'unet_cfg_tiny')
+    buf = OD.schedule_buffers(1000, 'cosine')
+    draws = [T(g[f'{obj}.draw{i}']) for i in range(8)]
+    # RNG order: randn(shape), then per step uniform(B) [, randn_like]
+    assert [tuple(d.shape) for d in draws] == [(2, 6, 16, 16)] + [(2,), (2, 6, 16, 16)] * 3 + [(2,)]
+    trace = []
+    with torch.no_grad():
+        img, mask, flow = OD.cfg_sample(sd, buf, T(g['classes']), T(g['rgb_flow01']), T(g['flow']), T(g['mask']),
+                                        image_size=16, channels=6, sampling_timesteps=4, objective=obj,
+                                        rng=OD.ReplayRng(draws), trace=trace)
+    tol = dict(rtol=1e-3, atol=1e-3) if obj != 'pred_x0' else dict(rtol=1e-3, atol=2e-4)
+    for i, st in enumerate(trace):
+        close(st['x_start'], g[f'{obj}.x_start{i}'], **tol)
+    close(img, g[f'{obj}.img'], **tol)
+    assert torch.equal(mask, T(g['mask'])) and torch.equal(flow, T(g['flow']))
+    assert float(img.min()) >= 0 and float(img.max()) <= 1
+
+
+def test_ddim_trace_seeded_stream(golden_dir, meta):
+    """the oracle's default RNG consumes torch's CPU stream in the reference's order"""
+    g = load(golden_dir, 'ddim_trace')
+    sd = sd_from(meta, 'unet_cfg_tiny')
+    buf = OD.schedule_buffers(1000, 'cosine')
+    torch.manual_seed(99)
+    rec = OD.RecordRng()
+    with torch.no_grad():
+        OD.cfg_sample(sd, buf, T(g['classes']), T(g['rgb_flow01']), T(g['flow']), T(g['mask']), image_size=16,
+                      channels=6, sampling_timesteps=4, objective='pred_x0', rng=rec)
+    assert len(rec.draws) == 8
+    for i, d in enumerate(rec.draws):
+        assert torch.equal(d, T(g[f'pred_x0.draw{i}'])), i
+
+
+# ------------------------------------------------------------------------- F6
+@pytest.mark.parametrize('tag', ['nosc', 'sc'])
+def test_ddpm_trace(golden_dir, meta, tag):
+    g = load(golden_dir, 'ddpm_trace')
+    sc = tag == 'sc'
+    sd = sd_from(meta, f'unet_ddp_tiny_{tag}', seed=1)
+    buf = OD.schedule_buffers(10, 'cosine')
+    with torch.no_grad():
+        draws = [T(g[f'{tag}.ddpm.draw{i}']) for i in range(10)]
+        img = OD.ddp_p_sample_loop(sd, buf, (2, 3, 16, 16), objective='pred_noise', self_condition=sc,
+                                   rng=OD.ReplayRng(draws))
+        close(img, g[f'{tag}.ddpm.img'], rtol=1e-3, atol=1e-4)
+        draws = [T(g[f'{tag}.ddim.draw{i}']) for i in range(4)]
+        img = OD.ddp_ddim_sample(sd, buf, (2, 3, 16, 16), sampling_timesteps=4, objective='pred_x0',
+                                 self_condition=sc, rng=OD.ReplayRng(draws))
+        close(img, g[f'{tag}.ddim.img'], rtol=1e-3, atol=1e-2)        # last 2 channels carry a x512 gain
+        if not sc:
+            pi, xs = OD.ddp_p_sample(sd, buf, T(g['p_sample.x']), 5, objective='pred_noise',
+                                     rng=OD.ReplayRng([T(g['p_sample.noise'])]))
+            close(pi, g['p_sample.img'])
+            close(xs, g['p_sample.x_start'])
+
+
+# ------------------------------------------------------------------------- F7
+def test_geometry(golden_dir):
+    g = load(golden_dir, 'geometry')
+    for tag, (h, w) in (('a', (128, 128)), ('b', (32, 48))):
+        for i, H0 in enumerate(g['H0']):
+            H1 = OG.adapt_homography(360, 640, H0, h, w)
+            np.testing.assert_allclose(H1, g[f'{tag}.H1'][i], rtol=1e-14, atol=1e-14)
+            flow = OG.homo_to_flow(g[f'{tag}.H1'][i], h, w)
+            assert flow.dtype == np.float32 and flow.shape == (h, w, 2)
+            np.testing.assert_allclose(flow, g[f'{tag}.flow'][i], rtol=0, atol=1e-5)
+            rgb = OG.flow_to_image(g[f'{tag}.flow'][i])
+            assert rgb.dtype == g[f'{tag}.rgb'].dtype
+            np.testing.assert_allclose(rgb, g[f'{tag}.rgb'][i], rtol=0, atol=1e-6)
+        ft = T(g[f'{tag}.flow']).permute(0, 3, 1, 2).contiguous()
+        close(OG.flow_warp(T(g[f'{tag}.img']), ft), g[f'{tag}.warp'], rtol=1e-5, atol=1e-6)
+    close(OG.flow_warp(T(g['r.img']), T(g['r.flow'])), g['r.warp'], rtol=1e-5, atol=1e-6)
+    # identity homography -> zero flow up to the 1e-6 w-perturbation (DDP:958-959)
+    assert np.abs(g['a.flow'][0]).max() < 2e-4
+    ft = T(g['b.flow']).permute(0, 3, 1, 2).contiguous()
+    hg = OG.homo_gen(ft)
+    np.testing.assert_allclose(hg.numpy(), g['b.homo_gen'], rtol=1e-7, atol=1e-9)
+    hn = OG.homo_gen_normal_eq(ft)
+    np.testing.assert_allclose(hn.numpy(), g['b.homo_gen'], rtol=1e-6, atol=1e-8)
+    # H -> flow -> H round trip (known-answer)
+    np.testing.assert_allclose(hg.numpy()[:, 0], g['b.H1'], rtol=2e-4, atol=2e-4)
+    img = T(g['b.img'])
+    ret = OG.save_train_pair(torch.cat([img, img.flip(0)], 1), ft)
+    assert ret['imgs'].dtype == np.uint8 and np.array_equal(ret['imgs'], g['b.pair_imgs'])
+    np.testing.assert_allclose(ret['homos'], g['b.pair_homos'], rtol=1e-7, atol=1e-9)
+
+
+def test_warp_known_answers():
+    img = torch.rand(2, 3, 9, 13, generator=torch.Generator().manual_seed(0))
+    # zero flow = identity up to the fp32 rounding of 2x/(W-1)-1 -> (g+1)(W-1)/2 (not bit-exact in the reference either)
+    torch.testing.assert_close(OG.flow_warp(img, torch.zeros(2, 2, 9, 13)), img, rtol=0, atol=1e-6)
+    pow2 = torch.rand(1, 2, 5, 9, generator=torch.Generator().manual_seed(1))   # W-1, H-1 powers of two: exact
+    assert torch.equal(OG.flow_warp(pow2, torch.zeros(1, 2, 5, 9)), pow2)
+    ix, iy, x0, y0 = OG.warp_coords(torch.full((1, 2, 9, 13), 100.))
+    assert int(x0.min()) == 12 and int(y0.min()) == 8                        # border clamp
