@@ -1,0 +1,256 @@
+"""Conditional UNet + GaussianDiffusion with classifier-free guidance on MI355X.
+
+Host-side mirror of the reference's
+``DGM/denoising_diffusion_models/classifier_free_guidance.py`` (tag CFG): same class
+names, constructor signatures, method names, ``state_dict`` keys and RNG call order,
+so scripts written against the reference (``DGM/dgm_sample.py:28-38``) run
+unchanged — but every tensor value is produced by the gfx950 kernels of
+libdmhomo_hip.so (see ``engine.py``).  There is no CPU path.
+"""
+from collections import namedtuple
+
+import torch
+from torch import nn
+
+from . import _params as P
+from . import ops
+from ._lib import DmhStep
+from .engine import UnetEngine
+from .schedule import make_buffers, ddim_pairs
+
+ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+class DeviceRng:
+    """draws with torch's generator of the target device, in the reference's call order
+    (CFG:679 randn(shape), CFG:90 zeros(B).uniform_(0,1), CFG:703 randn_like)."""
+
+    def randn(self, shape, device):
+        return torch.randn(tuple(shape), device=device)
+
+    def uniform(self, n, device):
+        return torch.zeros((n,), device=device).float().uniform_(0, 1)
+
+
+class Unet(nn.Module):
+    """CFG:302-466.  ``forward`` launches the HIP program; parameters live in holders."""
+
+    def __init__(self, dim, num_classes, cond_drop_prob=0.5, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8),
+                 channels=3, resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
+                 random_fourier_features=False, learned_sinusoidal_dim=16):
+        super().__init__()
+        self.cond_drop_prob = cond_drop_prob
+        self.channels = channels
+        input_channels = channels + 3                       # rgb_flow * mask is concatenated, CFG:330,430
+        init_dim = default(init_dim, dim)
+        self.init_conv = nn.Conv2d(input_channels, init_dim, 7, padding=3)
+        time_dim = dim * 4
+        self.random_or_learned_sinusoidal_cond = learned_sinusoidal_cond or random_fourier_features
+        if self.random_or_learned_sinusoidal_cond:
+            # CFG:514-515: GaussianDiffusion refuses such a model, so it cannot reach the sampling path
+            raise NotImplementedError('learned / random sinusoidal embeddings are outside the DGM sampling path')
+        self.time_mlp = nn.Sequential(P.Holder(), nn.Linear(dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
+        self.classes_emb = nn.Embedding(num_classes, dim)
+        self.null_classes_emb = nn.Parameter(torch.randn(dim))
+        classes_dim = dim * 4
+        self.classes_mlp = nn.Sequential(nn.Linear(dim, classes_dim), nn.GELU(), nn.Linear(classes_dim, classes_dim))
+        self.out_dim = default(out_dim, channels * (1 if not learned_variance else 2))
+        P.build_trunk(self, dim, init_dim, dim_mults, input_channels, time_dim + classes_dim, resnet_block_groups,
+                      self.out_dim, P.downsample_cfg)
+        self.rng = DeviceRng()
+        self._engine = UnetEngine(self, groups=resnet_block_groups)
+
+    # ---- class-dropout draw of CFG:421-425 / prob_mask_like CFG:84-90
+    def _keep_mask(self, batch, cond_drop_prob, device):
+        if not cond_drop_prob > 0:
+            return None
+        prob = 1 - cond_drop_prob
+        if prob == 1:
+            return None                                      # keep every row
+        if prob == 0:
+            return torch.zeros((batch,), device=device, dtype=torch.uint8)
+        return (self.rng.uniform(batch, device) < prob).to(torch.uint8)
+
+    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None):
+        """rows [rep*B + b]: sample b under class-keep mask keeps[rep] -> (len(keeps)*B, out_dim, H, W)."""
+        if not x.is_cuda:
+            raise RuntimeError('dmhomo_amd.Unet runs on the GPU only (HIP kernels); move the inputs with .cuda()')
+        eng = self._engine
+        eng.ensure_prepared()
+        x = x.to(torch.float32).contiguous()
+        rgb_flow = rgb_flow.to(torch.float32).contiguous()
+        mask = mask.to(torch.float32).contiguous()
+        time = time.to(torch.int64).contiguous()
+        classes = classes.to(torch.int64).contiguous()
+        xin = ops.assemble_input(x, rgb_flow, mask, reps=len(keeps), cpad=eng.cin_pad)
+        cond = eng.embed(time, [(classes, k) for k in keeps], len(keeps))
+        return eng.trunk(xin, cond, taps)
+
+    def forward(self, x, time, classes, rgb_flow, mask, cond_drop_prob=None):
+        cond_drop_prob = default(cond_drop_prob, self.cond_drop_prob)
+        keep = self._keep_mask(x.shape[0], cond_drop_prob, x.device)
+        return self._run(x, time, classes, rgb_flow, mask, [keep])
+
+    def _cond_null(self, x, time, classes, rgb_flow, mask):
+        """the two passes of CFG:404,409 as ONE batch of 2B rows: (cond logits, null logits)."""
+        B = x.shape[0]
+        keep = self._keep_mask(B, self.cond_drop_prob, x.device)
+        null = torch.zeros((B,), device=x.device, dtype=torch.uint8)
+        both = self._run(x, time, classes, rgb_flow, mask, [keep, null])
+        return both[:B], both[B:]
+
+    def forward_with_cond_scale(self, x, time, classes, rgb_flow, mask, cond_scale=1.):
+        if cond_scale == 1:
+            return self.forward(x, time, classes, rgb_flow, mask)
+        logits, null = self._cond_null(x, time, classes, rgb_flow, mask)
+        step = DmhStep(objective=ops.OBJECTIVE['pred_x0'], clip=0, mode=ops.MODE_LAST, cond_scale=float(cond_scale),
+                       sqrt_recip_ac=1., sqrt_recipm1_ac=1.)
+        out, _, _ = ops.sampler_step(step, logits, null, logits, None, want_x_start=False)
+        return out
+
+
+class ScheduleHost:
+    """host mirrors of the schedule buffers: the reference indexes device buffers with python ints and does
+    0-dim fp32 tensor arithmetic on them (CFG:697-701); here the same ops run on CPU copies and the results
+    enter the sampler kernel as scalars."""
+
+    def _host(self):
+        return {n: getattr(self, n).detach().cpu() for n in
+                ('alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod', 'sqrt_alphas_cumprod',
+                 'sqrt_one_minus_alphas_cumprod', 'posterior_mean_coef1', 'posterior_mean_coef2',
+                 'posterior_log_variance_clipped')}
+
+    def _ddim_coef(self, host, time, time_next):
+        """sqrt(alpha_next), c, sigma in the reference's op order, CFG:697-701."""
+        alpha = host['alphas_cumprod'][time]
+        alpha_next = host['alphas_cumprod'][time_next]
+        sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        c = (1 - alpha_next - sigma ** 2).sqrt()
+        return float(alpha_next.sqrt()), float(c), float(sigma)
+
+
+class GaussianDiffusion(nn.Module, ScheduleHost):
+    """CFG:498-842 — sampling side on the GPU kernels; buffers and their names as the reference."""
+
+    def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, loss_type='l1',
+                 objective='pred_noise', beta_schedule='cosine', p2_loss_weight_gamma=0., p2_loss_weight_k=1,
+                 ddim_sampling_eta=1.):
+        super().__init__()
+        assert not (type(self) == GaussianDiffusion and model.channels != model.out_dim)
+        assert not model.random_or_learned_sinusoidal_cond
+        self.model = model
+        self.channels = self.model.channels
+        self.image_size = image_size
+        self.objective = objective
+        assert objective in {'pred_noise', 'pred_x0', 'pred_v'}, \
+            'objective must be either pred_noise (predict noise) or pred_x0 (predict image start) or pred_v (predict v)'
+        bufs = make_buffers(beta_schedule, timesteps, p2_loss_weight_gamma, p2_loss_weight_k)
+        self.num_timesteps = int(bufs['betas'].shape[0])
+        self.loss_type = loss_type
+        self.sampling_timesteps = default(sampling_timesteps, timesteps)
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        for name, val in bufs.items():
+            self.register_buffer(name, val)
+
+    @property
+    def rng(self):
+        return self.model.rng
+
+    @rng.setter
+    def rng(self, value):
+        self.model.rng = value
+
+    def _step(self, host, t, mode, cond_scale, clip, c=(0., 0., 0.)):
+        return DmhStep(objective=ops.OBJECTIVE[self.objective], clip=int(bool(clip)), mode=mode,
+                       cond_scale=float(cond_scale),
+                       sqrt_recip_ac=float(host['sqrt_recip_alphas_cumprod'][t]),
+                       sqrt_recipm1_ac=float(host['sqrt_recipm1_alphas_cumprod'][t]),
+                       sqrt_ac=float(host['sqrt_alphas_cumprod'][t]),
+                       sqrt_1m_ac=float(host['sqrt_one_minus_alphas_cumprod'][t]),
+                       c0=float(c[0]), c1=float(c[1]), c2=float(c[2]))
+
+    def _uniform_time(self, t):
+        """python int when every sample shares the timestep (always true while sampling)."""
+        t0 = int(t[0])
+        if t.numel() > 1 and not bool((t == t0).all()):
+            raise NotImplementedError('dmhomo_amd.model_predictions expects one timestep per batch (as the samplers use)')
+        return t0
+
+    def _network(self, x, t, classes, rgb_flow, mask, cond_scale):
+        if cond_scale == 1:
+            return self.model.forward(x, t, classes, rgb_flow, mask), None
+        return self.model._cond_null(x, t, classes, rgb_flow, mask)
+
+    def model_predictions(self, x, t, classes, rgb_flow, mask, cond_scale=3., clip_x_start=False):
+        """CFG:610-630."""
+        host = self._host()
+        cond, null = self._network(x, t, classes, rgb_flow, mask, cond_scale)
+        step = self._step(host, self._uniform_time(t), ops.MODE_LAST, cond_scale, clip_x_start)
+        _, x_start, pred_noise = ops.sampler_step(step, cond, null, x.contiguous(), None, True, True)
+        return ModelPrediction(pred_noise, x_start)
+
+    @torch.no_grad()
+    def ddim_sample(self, classes, rgb_flow, flow, mask, shape, cond_scale=3., clip_denoised=True, trace=None):
+        """CFG:669-711.  ``trace`` (list) optionally receives per-step x_start / img for parity tests."""
+        batch, device = shape[0], self.betas.device
+        host = self._host()
+        img = self.rng.randn(shape, device).contiguous()
+        for time, time_next in ddim_pairs(self.num_timesteps, self.sampling_timesteps):
+            time_cond = torch.full((batch,), time, device=device, dtype=torch.long)
+            cond, null = self._network(img, time_cond, classes, rgb_flow, mask, cond_scale)
+            if time_next < 0:
+                step = self._step(host, time, ops.MODE_LAST, cond_scale, clip_denoised)
+                noise = None
+            else:
+                step = self._step(host, time, ops.MODE_DDIM, cond_scale, clip_denoised,
+                                  self._ddim_coef(host, time, time_next))
+                noise = self.rng.randn(shape, device).contiguous()
+            img, x_start, _ = ops.sampler_step(step, cond, null, img, noise, want_x_start=trace is not None)
+            if trace is not None:
+                trace.append({'time': time, 'x_start': x_start, 'img': img})
+        img = ops.affine(img, 0.5, 0.5)                      # unnormalize_to_zero_to_one, CFG:709
+        return img, mask, flow
+
+    @torch.no_grad()
+    def p_sample_loop(self, classes, shape, cond_scale=3.):
+        # CFG:656 takes (classes, shape, cond_scale) while CFG:719-720 calls it with six arguments, and
+        # CFG:633 mis-passes p_mean_variance's arguments: the reference's ancestral path cannot run
+        # (SURVEY.md fact 6).  Kept failing in the same way rather than inventing semantics.
+        raise TypeError('classifier_free_guidance.GaussianDiffusion.p_sample_loop is not callable in the reference '
+                        '(CFG:656 vs CFG:719-720); use sampling_timesteps < timesteps (DDIM), or the unconditional '
+                        'denoising_diffusion_pytorch.GaussianDiffusion for ancestral sampling')
+
+    @torch.no_grad()
+    def sample(self, classes, rgb_flow, flow, mask, cond_scale=3.):
+        """CFG:713-720."""
+        batch_size, image_size, channels = classes.shape[0], self.image_size, self.channels
+        shape = (batch_size, channels, image_size, image_size)
+        if not self.is_ddim_sampling:
+            return self.p_sample_loop(classes, rgb_flow, flow, mask, shape, cond_scale)    # TypeError, as CFG:719-720
+        rgb_flow = ops.affine(rgb_flow.to(torch.float32), 2., -1.)      # normalize_to_neg_one_to_one, CFG:716
+        return self.ddim_sample(classes, rgb_flow, flow, mask, shape, cond_scale)
+
+    def q_sample(self, x_start, t, noise=None):
+        """CFG:738-742."""
+        noise = default(noise, lambda: self.rng.randn(x_start.shape, x_start.device))
+        ca = self.sqrt_alphas_cumprod.gather(-1, t).contiguous()
+        cb = self.sqrt_one_minus_alphas_cumprod.gather(-1, t).contiguous()
+        return ops.q_sample(x_start.contiguous(), noise.contiguous(), ca, cb)
+
+    def p_losses(self, x_start, t, *, classes, rgb_flow, flow, mask, noise=None):
+        raise NotImplementedError('training (p_losses + backward kernels) is SURVEY.md §8f "next" row 1, not built yet')
+
+    def forward(self, img, *args, **kwargs):
+        raise NotImplementedError('training (GaussianDiffusion.forward -> p_losses) is SURVEY.md §8f "next" row 1')

@@ -1,0 +1,78 @@
+// K5 — time / class embeddings and the small dense layers (latency-bound, a few µs each).
+#include "common.h"
+
+// N7: out[r][i] = sin(t_r * f_i), out[r][half+i] = cos(t_r * f_i)   (t int64 -> fp32, CFG:170-171)
+__global__ void sinusoidal_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ freq,
+                                        float* __restrict__ out, int R, int dim) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (idx >= R * half) return;
+  const int r = idx / half, i = idx % half;
+  const float arg = (float)t[r] * freq[i];
+  out[(size_t)r * dim + i] = sinf(arg);
+  out[(size_t)r * dim + half + i] = cosf(arg);
+}
+
+// N8: classes_emb(classes) with rows swapped for null_classes_emb where keep == 0 (CFG:419-425)
+__global__ void class_embed_kernel(const int64_t* __restrict__ classes, const uint8_t* __restrict__ keep,
+                                   const float* __restrict__ table, const float* __restrict__ null_emb,
+                                   float* __restrict__ out, int R, int dim) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * dim) return;
+  const int r = idx / dim, i = idx % dim;
+  const bool k = keep ? (keep[r] != 0) : true;
+  out[idx] = k ? table[(size_t)classes[r] * dim + i] : null_emb[i];
+}
+
+__device__ __forceinline__ float act_f(float x, int act) {
+  if (act == 1) return silu_f(x);
+  if (act == 2) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));  // exact (erf) GELU
+  return x;
+}
+
+// y[r][o] = act_out(sum_i act_in(x[r][i]) * wt[i][o] + bias[o]); one row per blockIdx.y,
+// 256 output features per blockIdx.x, the (activated) input row staged in LDS.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int64_t x_stride,
+                                                     const float* __restrict__ wt, const float* __restrict__ bias,
+                                                     float* __restrict__ y, int64_t y_stride, int in_dim, int out_dim,
+                                                     int act_in, int act_out) {
+  extern __shared__ float xs[];
+  const int r = blockIdx.y;
+  for (int i = threadIdx.x; i < in_dim; i += 256) xs[i] = act_f(x[r * x_stride + i], act_in);
+  __syncthreads();
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= out_dim) return;
+  float acc = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < in_dim; ++i) acc = fmaf(xs[i], wt[(size_t)i * out_dim + o], acc);
+  if (bias) acc += bias[o];
+  y[r * y_stride + o] = act_f(acc, act_out);
+}
+
+extern "C" int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* out, int R, int dim, void* stream) {
+  DMH_REQUIRE(t && freq && out && R > 0 && dim > 0 && dim % 2 == 0, "dmh_sinusoidal_embed: bad arguments");
+  const int total = R * (dim / 2);
+  hipLaunchKernelGGL(sinusoidal_embed_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, t, freq, out,
+                     R, dim);
+  DMH_CHECK_LAUNCH("dmh_sinusoidal_embed");
+  return DMH_OK;
+}
+
+extern "C" int dmh_class_embed(const int64_t* classes, const uint8_t* keep, const float* table, const float* null_emb,
+                               float* out, int R, int dim, void* stream) {
+  DMH_REQUIRE(classes && table && null_emb && out && R > 0 && dim > 0, "dmh_class_embed: bad arguments");
+  hipLaunchKernelGGL(class_embed_kernel, dim3(cdiv(R * dim, 256)), dim3(256), 0, (hipStream_t)stream, classes, keep,
+                     table, null_emb, out, R, dim);
+  DMH_CHECK_LAUNCH("dmh_class_embed");
+  return DMH_OK;
+}
+
+extern "C" int dmh_linear(const float* x, int64_t x_stride, const float* wt, const float* bias, float* y,
+                          int64_t y_stride, int R, int in_dim, int out_dim, int act_in, int act_out, void* stream) {
+  DMH_REQUIRE(x && wt && y && R > 0 && in_dim > 0 && out_dim > 0, "dmh_linear: bad arguments");
+  DMH_REQUIRE(in_dim <= 8192, "dmh_linear: in_dim %d too large", in_dim);
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(out_dim, 256), R), dim3(256), in_dim * sizeof(float),
+                     (hipStream_t)stream, x, x_stride, wt, bias, y, y_stride, in_dim, out_dim, act_in, act_out);
+  DMH_CHECK_LAUNCH("dmh_linear");
+  return DMH_OK;
+}

@@ -1,0 +1,251 @@
+// K7-K9 — condition builder & geometry: homography -> flow -> HSV image, bilinear flow warp,
+// flow -> homography (DLT normal equations).  Mirrors the reference's op order exactly where
+// integers come out (grid-sample corner indices): no FMA contraction in this file.
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+// G3: flow_to_image DDP:1479-1485 + matplotlib.colors.hsv_to_rgb for one pixel
+__device__ __forceinline__ void flow_pixel_to_rgb(float u, float v, float max_flow, float& r, float& g, float& bl) {
+  const float n = 8.f;
+  const float mag = sqrtf(u * u + v * v);
+  const float ang = atan2f(v, u);
+  float hh = fmodf(ang / 6.283185307179586f + 1.f, 1.f);  // np.mod(angle / (2 pi) + 1, 1), operand >= 0.5
+  float ss = fminf(fmaxf(mag * n / max_flow, 0.f), 1.f);
+  float vv = fminf(fmaxf(n - ss, 0.f), 1.f);
+  // matplotlib.colors.hsv_to_rgb: i = (h*6).astype(int); f = h*6 - i is float64 there (f32 - int64),
+  // so q and t are formed in f64 and rounded to fp32 on store; p stays fp32.
+  const float h6 = hh * 6.0f;
+  const int i = (int)h6;
+  const double f = (double)h6 - (double)i;
+  const float pp = vv * (1.0f - ss);
+  const float qq = (float)((double)vv * (1.0 - (double)ss * f));
+  const float tt = (float)((double)vv * (1.0 - (double)ss * (1.0 - f)));
+  switch (i % 6) {
+    case 0: r = vv; g = tt; bl = pp; break;
+    case 1: r = qq; g = vv; bl = pp; break;
+    case 2: r = pp; g = vv; bl = tt; break;
+    case 3: r = pp; g = qq; bl = vv; break;
+    case 4: r = tt; g = pp; bl = vv; break;
+    default: r = vv; g = pp; bl = qq; break;
+  }
+  if (ss == 0.f) r = g = bl = vv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// G2 + G3.  get_flow_np DDP:954-967 in float64 on an integer grid, cast to fp32; then
+// flow_to_image DDP:1479-1485 + matplotlib hsv_to_rgb in fp32.
+__global__ __launch_bounds__(256) void homography_flow_kernel(const double* __restrict__ Hm, float* __restrict__ flow,
+                                                              float* __restrict__ rgb, int H, int W, float max_flow) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int yi = p / W, xi = p % W;
+  const double* h = Hm + b * 9;
+  const double x = (double)xi, y = (double)yi;
+  const double qx = h[0] * x + h[1] * y + h[2];
+  const double qy = h[3] * x + h[4] * y + h[5];
+  const double qw = (h[6] * x + h[7] * y + h[8]) + 1e-6;  // DDP:958-959
+  const float u = (float)(qx / qw - x);
+  const float v = (float)(qy / qw - y);
+  const size_t hw = (size_t)H * W;
+  if (flow) {
+    flow[((size_t)b * 2 + 0) * hw + p] = u;
+    flow[((size_t)b * 2 + 1) * hw + p] = v;
+  }
+  if (rgb) {
+    float r, g, bl;
+    flow_pixel_to_rgb(u, v, max_flow, r, g, bl);
+    rgb[((size_t)b * 3 + 0) * hw + p] = r;
+    rgb[((size_t)b * 3 + 1) * hw + p] = g;
+    rgb[((size_t)b * 3 + 2) * hw + p] = bl;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// G4.  flow_warp = grid_sample(bilinear, border, align_corners=True) of torch's CPU kernel:
+//   g  = 2.0*v/(W-1) - 1.0;  ix = (g+1)*((W-1)/2);  ix = min(W-1, max(ix, 0));  x0 = floor(ix)
+//   w = ix-x0, e = (x0+1)-ix, n = iy-y0, s = (y0+1)-iy
+//   out = fma(se, n*w, fma(sw, n*e, fma(ne, s*w, nw*(s*e))))
+__global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                        float* __restrict__ out, int32_t* __restrict__ x0o,
+                                                        int32_t* __restrict__ y0o, int C, int H, int W) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int yi = p / W, xi = p % W;
+  const size_t hw = (size_t)H * W;
+  const float vx = (float)xi + flow[((size_t)b * 2 + 0) * hw + p];
+  const float vy = (float)yi + flow[((size_t)b * 2 + 1) * hw + p];
+  const float gx = 2.0f * vx / (float)(W - 1) - 1.0f;
+  const float gy = 2.0f * vy / (float)(H - 1) - 1.0f;
+  float ix = (gx + 1.f) * ((float)(W - 1) / 2.f);
+  float iy = (gy + 1.f) * ((float)(H - 1) / 2.f);
+  ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+  iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  if (x0o) x0o[(size_t)b * hw + p] = x0;
+  if (y0o) y0o[(size_t)b * hw + p] = y0;
+  const float w = ix - fx0, e = (fx0 + 1.f) - ix, n = iy - fy0, s = (fy0 + 1.f) - iy;
+  const float wnw = s * e, wne = s * w, wsw = n * e, wse = n * w;
+  const bool x1ok = x0 + 1 <= W - 1, y1ok = y0 + 1 <= H - 1;
+  const int x1 = x1ok ? x0 + 1 : x0, y1 = y1ok ? y0 + 1 : y0;
+  for (int c = 0; c < C; ++c) {
+    const float* xc = x + ((size_t)b * C + c) * hw;
+    const float nw = xc[(size_t)y0 * W + x0];
+    const float ne = x1ok ? xc[(size_t)y0 * W + x1] : 0.f;
+    const float sw = y1ok ? xc[(size_t)y1 * W + x0] : 0.f;
+    const float se = (x1ok && y1ok) ? xc[(size_t)y1 * W + x1] : 0.f;
+    float acc = nw * wnw;
+    acc = fmaf(ne, wne, acc);
+    acc = fmaf(sw, wsw, acc);
+    acc = fmaf(se, wse, acc);
+    out[((size_t)b * C + c) * hw + p] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// G5.  DLT_solve DDP:1612-1643 for one homography per sample: least squares over all pixels,
+//   [x y 1 0 0 0 -x'x -x'y] h = x',  [0 0 0 x y 1 -y'x -y'y] h = y',  (x',y') = (x,y) + flow.
+// pinv(A) b == (A^T A)^-1 A^T b for full column rank; A^T A (36 unique) and A^T b (8) are
+// accumulated in f64 per block (fixed order), then a second kernel sums the blocks and solves
+// the column-equilibrated 8x8 system by Cholesky.
+__device__ __forceinline__ void dlt_accum(double* acc, const double* r, double rhs) {
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = i; j < 8; ++j) acc[k++] += r[i] * r[j];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[36 + i] += r[i] * rhs;
+}
+
+__global__ __launch_bounds__(256) void dlt_accumulate_kernel(const float* __restrict__ flow, double* __restrict__ ws,
+                                                             int H, int W) {
+  __shared__ double red[4][44];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  const size_t hw = (size_t)H * W;
+  double acc[44];
+#pragma unroll
+  for (int i = 0; i < 44; ++i) acc[i] = 0.0;
+  for (int p = blk * 256 + threadIdx.x; p < (int)hw; p += DMH_DLT_BLOCKS * 256) {
+    const double x = (double)(p % W), y = (double)(p / W);
+    const double xd = x + (double)flow[((size_t)b * 2 + 0) * hw + p];
+    const double yd = y + (double)flow[((size_t)b * 2 + 1) * hw + p];
+    const double ru[8] = {x, y, 1.0, 0.0, 0.0, 0.0, -xd * x, -xd * y};
+    const double rv[8] = {0.0, 0.0, 0.0, x, y, 1.0, -yd * x, -yd * y};
+    dlt_accum(acc, ru, xd);
+    dlt_accum(acc, rv, yd);
+  }
+#pragma unroll
+  for (int i = 0; i < 44; ++i) {
+    double v = acc[i];
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    acc[i] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 44; ++i) red[wave][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 44)
+    ws[((size_t)b * DMH_DLT_BLOCKS + blk) * 44 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void dlt_solve_kernel(const double* __restrict__ ws, double* __restrict__ Hout, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s[44];
+  for (int i = 0; i < 44; ++i) s[i] = 0.0;
+  for (int blk = 0; blk < DMH_DLT_BLOCKS; ++blk)
+    for (int i = 0; i < 44; ++i) s[i] += ws[((size_t)b * DMH_DLT_BLOCKS + blk) * 44 + i];
+  double G[8][8], r[8], d[8];
+  int k = 0;
+  for (int i = 0; i < 8; ++i)
+    for (int j = i; j < 8; ++j) {
+      G[i][j] = s[k];
+      G[j][i] = s[k];
+      ++k;
+    }
+  for (int i = 0; i < 8; ++i) d[i] = 1.0 / sqrt(G[i][i]);
+  for (int i = 0; i < 8; ++i) {
+    r[i] = s[36 + i] * d[i];
+    for (int j = 0; j < 8; ++j) G[i][j] *= d[i] * d[j];
+  }
+  // Cholesky G = L L^T (in the lower triangle)
+  for (int j = 0; j < 8; ++j) {
+    double v = G[j][j];
+    for (int q = 0; q < j; ++q) v -= G[j][q] * G[j][q];
+    const double ljj = sqrt(v);
+    G[j][j] = ljj;
+    for (int i = j + 1; i < 8; ++i) {
+      double t = G[i][j];
+      for (int q = 0; q < j; ++q) t -= G[i][q] * G[j][q];
+      G[i][j] = t / ljj;
+    }
+  }
+  double yv[8], hv[8];
+  for (int i = 0; i < 8; ++i) {
+    double t = r[i];
+    for (int q = 0; q < i; ++q) t -= G[i][q] * yv[q];
+    yv[i] = t / G[i][i];
+  }
+  for (int i = 7; i >= 0; --i) {
+    double t = yv[i];
+    for (int q = i + 1; q < 8; ++q) t -= G[q][i] * hv[q];
+    hv[i] = t / G[i][i];
+  }
+  for (int i = 0; i < 8; ++i) Hout[(size_t)b * 9 + i] = hv[i] * d[i];
+  Hout[(size_t)b * 9 + 8] = 1.0;
+}
+
+extern "C" int dmh_homography_flow(const double* Hm, float* flow, float* rgb, int B, int H, int W, float max_flow,
+                                   void* stream) {
+  DMH_REQUIRE(Hm && (flow || rgb) && B > 0 && H > 0 && W > 0, "dmh_homography_flow: bad arguments");
+  hipLaunchKernelGGL(homography_flow_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, Hm, flow,
+                     rgb, H, W, max_flow);
+  DMH_CHECK_LAUNCH("dmh_homography_flow");
+  return DMH_OK;
+}
+
+__global__ __launch_bounds__(256) void flow_image_kernel(const float* __restrict__ flow, float* __restrict__ rgb,
+                                                         int HW, float max_flow) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  float r, g, bl;
+  flow_pixel_to_rgb(flow[((size_t)b * 2 + 0) * HW + p], flow[((size_t)b * 2 + 1) * HW + p], max_flow, r, g, bl);
+  rgb[((size_t)b * 3 + 0) * HW + p] = r;
+  rgb[((size_t)b * 3 + 1) * HW + p] = g;
+  rgb[((size_t)b * 3 + 2) * HW + p] = bl;
+}
+
+extern "C" int dmh_flow_to_image(const float* flow, float* rgb, int B, int HW, float max_flow, void* stream) {
+  DMH_REQUIRE(flow && rgb && B > 0 && HW > 0, "dmh_flow_to_image: bad arguments");
+  hipLaunchKernelGGL(flow_image_kernel, dim3(cdiv(HW, 256), B), dim3(256), 0, (hipStream_t)stream, flow, rgb, HW,
+                     max_flow);
+  DMH_CHECK_LAUNCH("dmh_flow_to_image");
+  return DMH_OK;
+}
+
+extern "C" int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, int32_t* y0, int B, int C,
+                             int H, int W, void* stream) {
+  DMH_REQUIRE(x && flow && out && B > 0 && C > 0 && H > 1 && W > 1, "dmh_flow_warp: bad arguments");
+  hipLaunchKernelGGL(flow_warp_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, x, flow, out, x0,
+                     y0, C, H, W);
+  DMH_CHECK_LAUNCH("dmh_flow_warp");
+  return DMH_OK;
+}
+
+extern "C" int dmh_dlt_homography(const float* flow, double* ws, double* Hout, int B, int H, int W, void* stream) {
+  DMH_REQUIRE(flow && ws && Hout && B > 0 && H > 0 && W > 0, "dmh_dlt_homography: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dlt_accumulate_kernel, dim3(DMH_DLT_BLOCKS, B), dim3(256), 0, st, flow, ws, H, W);
+  DMH_CHECK_LAUNCH("dmh_dlt_homography(accumulate)");
+  hipLaunchKernelGGL(dlt_solve_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, ws, Hout, B);
+  DMH_CHECK_LAUNCH("dmh_dlt_homography(solve)");
+  return DMH_OK;
+}

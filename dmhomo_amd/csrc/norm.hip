@@ -1,0 +1,181 @@
+// GroupNorm finalisation, GN+SiLU+residual, channel LayerNorm — the HBM-bound glue between
+// the matrix-core kernels.  NHWC fp32, 16 B per lane per access.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// N2: reduce the per-tile (sum, sum^2) partials of dmh_conv2d for one (sample, group) in f64 and
+// emit the affine the consumer applies:  y = a*x + b  ==  ((x-mean)*rstd*gamma+beta)*(scale+1)+shift
+// One wave per (sample, group); fixed reduction order.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ stats, int tiles,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ ss,
+                                                         int64_t ss_stride, float* __restrict__ coef, int C, int groups,
+                                                         int hw, float eps) {
+  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int cg = C / groups;
+  const int lane = threadIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  const int total = tiles * cg;
+  for (int i = lane; i < total; i += 64) {
+    const int tile = i / cg, cc = i % cg;
+    const float* st = stats + ((size_t)(b * tiles + tile) * C + g * cg + cc) * 2;
+    s1 += (double)st[0];
+    s2 += (double)st[1];
+  }
+  for (int off = 32; off; off >>= 1) {
+    s1 += __shfl_xor(s1, off);
+    s2 += __shfl_xor(s2, off);
+  }
+  const double n = (double)hw * (double)cg;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  for (int cc = lane; cc < cg; cc += 64) {
+    const int c = g * cg + cc;
+    float a = rstd * gamma[c];
+    float bb = beta[c] - meanf * a;
+    if (ss) {
+      const float sc = ss[b * ss_stride + c] + 1.0f;
+      const float sh = ss[b * ss_stride + C + c];
+      a = a * sc;
+      bb = fmaf(bb, sc, sh);
+    }
+    coef[(size_t)(b * 2 + 0) * C + c] = a;
+    coef[(size_t)(b * 2 + 1) * C + c] = bb;
+  }
+}
+
+// out = SiLU(a*y + b) + res, elementwise NHWC, a/b per (sample, channel)
+__global__ __launch_bounds__(256) void gn_silu_residual_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ coef,
+                                                               const float* __restrict__ res, float* __restrict__ out,
+                                                               int64_t per_sample4, int C, int64_t total4) {
+  const int C4 = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / per_sample4);
+    const int c = (int)(i % C4) * 4;
+    const float4 a = ld4(coef + (size_t)(b * 2 + 0) * C + c);
+    const float4 bb = ld4(coef + (size_t)(b * 2 + 1) * C + c);
+    const float4 v = ld4(y + i * 4);
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) r = ld4(res + i * 4);
+    float4 o;
+    o.x = silu_f(fmaf(a.x, v.x, bb.x)) + r.x;
+    o.y = silu_f(fmaf(a.y, v.y, bb.y)) + r.y;
+    o.z = silu_f(fmaf(a.z, v.z, bb.z)) + r.z;
+    o.w = silu_f(fmaf(a.w, v.w, bb.w)) + r.w;
+    st4(out + i * 4, o);
+  }
+}
+
+// N4: per-pixel LayerNorm over the (contiguous) channel axis. LPP lanes share a pixel, each
+// holding NV float4; two-pass (mean, then centred second moment) in registers.
+template <int LPP, int NV>
+__global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                             const float* __restrict__ res, float* __restrict__ out,
+                                                             int64_t npix, int C, float eps) {
+  const int C4 = C >> 2;
+  const int sub = threadIdx.x % LPP;
+  const int64_t pix_per_block = 256 / LPP;
+  for (int64_t pix = (int64_t)blockIdx.x * pix_per_block + threadIdx.x / LPP; pix < npix;
+       pix += (int64_t)gridDim.x * pix_per_block) {
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < C4) v[j] = ld4(x + pix * C + q * 4);
+      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+#pragma unroll
+    for (int off = LPP >> 1; off; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float qsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      if (q < C4) {
+        const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+        qsum += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+    }
+#pragma unroll
+    for (int off = LPP >> 1; off; off >>= 1) qsum += __shfl_xor(qsum, off);
+    const float rstd = 1.0f / sqrtf(qsum / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      if (q < C4) {
+        const float4 gg = ld4(g + q * 4);
+        float4 o;
+        o.x = (v[j].x - mean) * rstd * gg.x;
+        o.y = (v[j].y - mean) * rstd * gg.y;
+        o.z = (v[j].z - mean) * rstd * gg.z;
+        o.w = (v[j].w - mean) * rstd * gg.w;
+        if (res) {
+          const float4 r = ld4(res + pix * C + q * 4);
+          o.x += r.x;
+          o.y += r.y;
+          o.z += r.z;
+          o.w += r.w;
+        }
+        st4(out + pix * C + q * 4, o);
+      }
+    }
+  }
+}
+
+extern "C" int dmh_gn_finalize(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
+                               int64_t ss_stride, float* coef, int B, int C, int groups, int hw, float eps,
+                               void* stream) {
+  DMH_REQUIRE(stats && gamma && beta && coef, "dmh_gn_finalize: null pointer");
+  DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize: bad shape");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
+                     ss, ss_stride, coef, C, groups, hw, eps);
+  DMH_CHECK_LAUNCH("dmh_gn_finalize");
+  return DMH_OK;
+}
+
+extern "C" int dmh_gn_silu_residual(const float* y, const float* coef, const float* res, float* out, int B, int HW,
+                                    int C, void* stream) {
+  DMH_REQUIRE(y && coef && out, "dmh_gn_silu_residual: null pointer");
+  DMH_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "dmh_gn_silu_residual: bad shape (C %% 4 != 0?)");
+  const int64_t per_sample4 = (int64_t)HW * C / 4;
+  const int64_t total4 = per_sample4 * B;
+  const unsigned grid = (unsigned)(cdiv64(total4, 256) < 8192 ? cdiv64(total4, 256) : 8192);
+  hipLaunchKernelGGL(gn_silu_residual_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, coef, res, out,
+                     per_sample4, C, total4);
+  DMH_CHECK_LAUNCH("dmh_gn_silu_residual");
+  return DMH_OK;
+}
+
+template <int LPP, int NV>
+static int launch_ln(const float* x, const float* g, const float* res, float* out, int64_t npix, int C, float eps,
+                     hipStream_t st) {
+  const int64_t ppb = 256 / LPP;
+  const int64_t need = cdiv64(npix, ppb);
+  const unsigned grid = (unsigned)(need < 16384 ? need : 16384);
+  hipLaunchKernelGGL((chan_layernorm_kernel<LPP, NV>), dim3(grid), dim3(256), 0, st, x, g, res, out, npix, C, eps);
+  DMH_CHECK_LAUNCH("dmh_chan_layernorm");
+  return DMH_OK;
+}
+
+extern "C" int dmh_chan_layernorm(const float* x, const float* g, const float* res, float* out, int64_t npix, int C,
+                                  float eps, void* stream) {
+  DMH_REQUIRE(x && g && out, "dmh_chan_layernorm: null pointer");
+  DMH_REQUIRE(npix > 0 && C > 0 && C % 4 == 0 && C <= 2048, "dmh_chan_layernorm: unsupported C=%d", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int C4 = C / 4;
+  if (C4 <= 2) return launch_ln<2, 1>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 4) return launch_ln<4, 1>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 8) return launch_ln<8, 1>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 16) return launch_ln<16, 1>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 32) return launch_ln<32, 1>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 64) return launch_ln<64, 1>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 128) return launch_ln<64, 2>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 256) return launch_ln<64, 4>(x, g, res, out, npix, C, eps, st);
+  return launch_ln<64, 8>(x, g, res, out, npix, C, eps, st);
+}

@@ -1,0 +1,223 @@
+// K6 — the elementwise glue of the sampling loop at the NCHW API boundary: network input
+// assembly, final 1x1 conv back to NCHW, classifier-free-guidance blend + x0 clamp + DDIM /
+// DDPM update, uint8 export.  Mirrors the reference's fp32 op order (no FMA contraction).
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+// out NHWC [reps*B][HW][Cpad] <- cat(a, b*m) zero padded; sample r reads source r % B
+__global__ __launch_bounds__(256) void assemble_input_kernel(const float* __restrict__ a, int Ca,
+                                                             const float* __restrict__ b, int Cb,
+                                                             const float* __restrict__ m, float* __restrict__ out,
+                                                             int B, int HW, int Cpad, int64_t total) {
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c = (int)(idx % Cpad);
+    const int64_t rp = idx / Cpad;
+    const int p = (int)(rp % HW);
+    const int r = (int)(rp / HW);
+    const int s = r % B;
+    float v = 0.f;
+    if (c < Ca) {
+      v = a[((size_t)s * Ca + c) * HW + p];
+    } else if (c < Ca + Cb) {
+      v = b[((size_t)s * Cb + (c - Ca)) * HW + p];
+      if (m) v = v * m[(size_t)s * HW + p];
+    }
+    out[idx] = v;
+  }
+}
+
+// final_conv: 16 lanes per pixel, each a float4 slice of the channels; Cout <= 16 dot products
+// reduced over the 16 lanes with shuffles, written NCHW.
+template <int COUT>
+__global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int64_t npix, int HW, int C) {
+  const int sub = threadIdx.x & 15;
+  const int C4 = C >> 2;
+  for (int64_t pix = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (int64_t)gridDim.x * 16) {
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int q = sub; q < C4; q += 16) {
+      const float4 v = ld4(x + pix * C + q * 4);
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) {
+        const float4 ww = ld4(w + (size_t)o * C + q * 4);
+        acc[o] = fmaf(v.x, ww.x, acc[o]);
+        acc[o] = fmaf(v.y, ww.y, acc[o]);
+        acc[o] = fmaf(v.z, ww.z, acc[o]);
+        acc[o] = fmaf(v.w, ww.w, acc[o]);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+#pragma unroll
+      for (int off = 8; off; off >>= 1) acc[o] += __shfl_xor(acc[o], off);
+    }
+    if (sub == 0) {
+      const int64_t r = pix / HW;
+      const int p = (int)(pix % HW);
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) out[((size_t)r * COUT + o) * HW + p] = acc[o] + (bias ? bias[o] : 0.f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sampler_step_kernel(DmhStep s, const float* __restrict__ mc,
+                                                           const float* __restrict__ mn, const float* __restrict__ x,
+                                                           const float* __restrict__ noise, float* __restrict__ img_out,
+                                                           float* __restrict__ x_start, float* __restrict__ pred_noise,
+                                                           int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float mo = mc[i];
+    if (mn) {
+      const float nl = mn[i];
+      mo = nl + (mo - nl) * s.cond_scale;  // CFG:410
+    }
+    const float xt = x[i];
+    float x0, pn;
+    if (s.objective == 0) {  // pred_noise, CFG:614-617
+      pn = mo;
+      x0 = s.sqrt_recip_ac * xt - s.sqrt_recipm1_ac * pn;
+      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    } else if (s.objective == 1) {  // pred_x0, CFG:619-622
+      x0 = mo;
+      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
+    } else {  // pred_v, CFG:624-628
+      x0 = s.sqrt_ac * xt - s.sqrt_1m_ac * mo;
+      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
+    }
+    float o;
+    if (s.mode == 0) {  // DDIM, CFG:705-707
+      o = x0 * s.c0 + s.c1 * pn + s.c2 * noise[i];
+    } else if (s.mode == 1) {  // last DDIM step, CFG:693-695
+      o = x0;
+    } else {  // DDPM posterior step, DDP:604-611,660: mean + exp(.5 logvar) * noise (noise == NULL at t == 0)
+      o = s.c0 * x0 + s.c1 * xt;
+      if (noise) o = o + s.c2 * noise[i];
+    }
+    img_out[i] = o;
+    if (x_start) x_start[i] = x0;
+    if (pred_noise) pred_noise[i] = pn;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_tail_kernel(float* __restrict__ x, int C, int HW, int c0, float scale,
+                                                          float shift, int64_t total) {
+  const int64_t per = (int64_t)(C - c0) * HW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / per, r = i % per;
+    float* p = x + (b * C + c0) * HW + r;
+    *p = *p * scale + shift;
+  }
+}
+
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                                       const float* __restrict__ ca, const float* __restrict__ cb,
+                                                       float* __restrict__ out, int64_t per_sample, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / per_sample);
+    out[i] = ca[b] * x0[i] + cb[b] * noise[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, float* __restrict__ y, float scale,
+                                                     float shift, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = x[i] * scale + shift;
+}
+
+__global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__ img, uint8_t* __restrict__ out,
+                                                       int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = img[i] * 255.f;
+    out[i] = (uint8_t)(int)v;  // numpy astype(uint8) of a float in [0, 255]: truncation
+  }
+}
+
+static unsigned grid_for(int64_t n, int per_block = 256) {
+  const int64_t g = cdiv64(n, per_block);
+  return (unsigned)(g < 16384 ? (g > 0 ? g : 1) : 16384);
+}
+
+extern "C" int dmh_assemble_input(const float* a, int Ca, const float* b, int Cb, const float* m, float* out, int B,
+                                  int reps, int HW, int Cpad, void* stream) {
+  DMH_REQUIRE(a && out && B > 0 && reps > 0 && HW > 0 && Ca > 0 && Cb >= 0, "dmh_assemble_input: bad arguments");
+  DMH_REQUIRE(Cpad % 4 == 0 && Cpad >= Ca + Cb, "dmh_assemble_input: Cpad=%d must be a multiple of 4 >= %d", Cpad,
+              Ca + Cb);
+  DMH_REQUIRE(Cb == 0 || b, "dmh_assemble_input: b is NULL with Cb > 0");
+  const int64_t total = (int64_t)reps * B * HW * Cpad;
+  hipLaunchKernelGGL(assemble_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, Ca, b, Cb, m,
+                     out, B, HW, Cpad, total);
+  DMH_CHECK_LAUNCH("dmh_assemble_input");
+  return DMH_OK;
+}
+
+extern "C" int dmh_final_conv_nchw(const float* x, const float* w, const float* bias, float* out, int R, int HW, int C,
+                                   int Cout, void* stream) {
+  DMH_REQUIRE(x && w && out && R > 0 && HW > 0 && C > 0 && C % 4 == 0, "dmh_final_conv_nchw: bad arguments");
+  const int64_t npix = (int64_t)R * HW;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(grid_for(npix, 16));
+#define DMH_FC(N)                                                                                             \
+  case N:                                                                                                     \
+    hipLaunchKernelGGL((final_conv_kernel<N>), grid, dim3(256), 0, st, x, w, bias, out, npix, HW, C); \
+    break;
+  switch (Cout) {
+    DMH_FC(1) DMH_FC(2) DMH_FC(3) DMH_FC(4) DMH_FC(6) DMH_FC(8) DMH_FC(12) DMH_FC(16)
+    default:
+      dmh_set_error("dmh_final_conv_nchw: unsupported Cout=%d (1,2,3,4,6,8,12,16)", Cout);
+      return DMH_EINVAL;
+  }
+#undef DMH_FC
+  DMH_CHECK_LAUNCH("dmh_final_conv_nchw");
+  return DMH_OK;
+}
+
+extern "C" int dmh_sampler_step(const DmhStep* s, const float* model_cond, const float* model_null, const float* x,
+                                const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
+                                void* stream) {
+  DMH_REQUIRE(s && model_cond && x && img_out && n > 0, "dmh_sampler_step: bad arguments");
+  DMH_REQUIRE(s->objective >= 0 && s->objective <= 2 && s->mode >= 0 && s->mode <= 2, "dmh_sampler_step: bad enum");
+  DMH_REQUIRE(s->mode != 0 || noise, "dmh_sampler_step: DDIM update needs noise");
+  hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *s, model_cond,
+                     model_null, x, noise, img_out, x_start, pred_noise, n);
+  DMH_CHECK_LAUNCH("dmh_sampler_step");
+  return DMH_OK;
+}
+
+extern "C" int dmh_affine(const float* x, float* y, float scale, float shift, int64_t n, void* stream) {
+  DMH_REQUIRE(x && y && n > 0, "dmh_affine: bad arguments");
+  hipLaunchKernelGGL(affine_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, scale, shift, n);
+  DMH_CHECK_LAUNCH("dmh_affine");
+  return DMH_OK;
+}
+
+extern "C" int dmh_affine_tail(float* x, int B, int C, int HW, int c0, float scale, float shift, void* stream) {
+  DMH_REQUIRE(x && B > 0 && C > 0 && HW > 0 && c0 >= 0 && c0 < C, "dmh_affine_tail: bad arguments");
+  const int64_t total = (int64_t)B * (C - c0) * HW;
+  hipLaunchKernelGGL(affine_tail_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, C, HW, c0, scale,
+                     shift, total);
+  DMH_CHECK_LAUNCH("dmh_affine_tail");
+  return DMH_OK;
+}
+
+extern "C" int dmh_q_sample(const float* x_start, const float* noise, const float* ca, const float* cb, float* out,
+                            int B, int64_t per_sample, void* stream) {
+  DMH_REQUIRE(x_start && noise && ca && cb && out && B > 0 && per_sample > 0, "dmh_q_sample: bad arguments");
+  const int64_t total = (int64_t)B * per_sample;
+  hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_start, noise, ca, cb,
+                     out, per_sample, total);
+  DMH_CHECK_LAUNCH("dmh_q_sample");
+  return DMH_OK;
+}
+
+extern "C" int dmh_to_uint8(const float* img, uint8_t* out, int64_t n, void* stream) {
+  DMH_REQUIRE(img && out && n > 0, "dmh_to_uint8: bad arguments");
+  hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, img, out, n);
+  DMH_CHECK_LAUNCH("dmh_to_uint8");
+  return DMH_OK;
+}

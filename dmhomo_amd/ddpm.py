@@ -1,0 +1,344 @@
+"""Unconditional UNet + GaussianDiffusion + Trainer + geometry helpers on MI355X.
+
+Host-side mirror of ``DGM/denoising_diffusion_models/denoising_diffusion_pytorch.py`` (tag DDP):
+``Unet`` DDP:315-447, ``GaussianDiffusion`` DDP:481-817 (``p_sample`` / ``p_sample_loop`` /
+``ddim_sample`` are the functions BASELINE.json's north_star names), the condition-builder
+helpers DDP:913-988,1262-1299,1471-1486,1558-1678 and the ``Trainer`` surface DDP:1681-2021.
+All tensor values come from libdmhomo_hip.so; there is no CPU path.
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _params as P
+from . import ops
+from ._lib import DmhStep
+from .cfg import DeviceRng, ModelPrediction, ScheduleHost, default, exists
+from .engine import UnetEngine
+from .schedule import make_buffers, ddim_pairs
+
+__version__ = '0.1.0'
+
+
+class Unet(nn.Module):
+    """DDP:315-447 (pixel-unshuffle Downsample, optional self-conditioning, time embedding only)."""
+
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3, self_condition=False,
+                 resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
+                 random_fourier_features=False, learned_sinusoidal_dim=16):
+        super().__init__()
+        self.channels = channels
+        self.self_condition = self_condition
+        input_channels = channels * (2 if self_condition else 1)
+        init_dim = default(init_dim, dim)
+        self.init_conv = nn.Conv2d(input_channels, init_dim, 7, padding=3)
+        time_dim = dim * 4
+        self.random_or_learned_sinusoidal_cond = learned_sinusoidal_cond or random_fourier_features
+        if self.random_or_learned_sinusoidal_cond:
+            raise NotImplementedError('learned / random sinusoidal embeddings are outside the DGM sampling path')
+        self.time_mlp = nn.Sequential(P.Holder(), nn.Linear(dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
+        self.out_dim = default(out_dim, channels * (1 if not learned_variance else 2))
+        P.build_trunk(self, dim, init_dim, dim_mults, input_channels, time_dim, resnet_block_groups, self.out_dim,
+                      P.downsample_ddp)
+        self._engine = UnetEngine(self, groups=resnet_block_groups)
+
+    def forward(self, x, time, x_self_cond=None):
+        if not x.is_cuda:
+            raise RuntimeError('dmhomo_amd.Unet runs on the GPU only (HIP kernels); move the inputs with .cuda()')
+        eng = self._engine
+        eng.ensure_prepared()
+        x = x.to(torch.float32).contiguous()
+        time = time.to(torch.int64).contiguous()
+        if self.self_condition:
+            sc = default(x_self_cond, lambda: torch.zeros_like(x)).to(torch.float32).contiguous()
+            xin = ops.assemble_input(sc, x, None, cpad=eng.cin_pad)          # cat((x_self_cond, x)), DDP:411
+        else:
+            xin = ops.assemble_input(x, None, None, cpad=eng.cin_pad)
+        cond = eng.embed(time, None, 1)
+        return eng.trunk(xin, cond)
+
+
+class GaussianDiffusion(nn.Module, ScheduleHost):
+    """DDP:481-817, sampling side."""
+
+    def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, loss_type='l1',
+                 objective='pred_noise', beta_schedule='cosine', p2_loss_weight_gamma=0., p2_loss_weight_k=1,
+                 ddim_sampling_eta=1.):
+        super().__init__()
+        assert not (type(self) == GaussianDiffusion and model.channels != model.out_dim)
+        assert not model.random_or_learned_sinusoidal_cond
+        self.model = model
+        self.channels = self.model.channels
+        self.self_condition = self.model.self_condition
+        self.image_size = image_size
+        self.objective = objective
+        assert objective in {'pred_noise', 'pred_x0', 'pred_v'}, \
+            'objective must be either pred_noise (predict noise) or pred_x0 (predict image start) or pred_v (predict v)'
+        bufs = make_buffers(beta_schedule, timesteps, p2_loss_weight_gamma, p2_loss_weight_k)
+        self.num_timesteps = int(bufs['betas'].shape[0])
+        self.loss_type = loss_type
+        self.sampling_timesteps = default(sampling_timesteps, timesteps)
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        for name, val in bufs.items():
+            self.register_buffer(name, val)
+        self.rng = DeviceRng()
+
+    def _step(self, host, t, mode, clip, c=(0., 0., 0.)):
+        return DmhStep(objective=ops.OBJECTIVE[self.objective], clip=int(bool(clip)), mode=mode, cond_scale=1.,
+                       sqrt_recip_ac=float(host['sqrt_recip_alphas_cumprod'][t]),
+                       sqrt_recipm1_ac=float(host['sqrt_recipm1_alphas_cumprod'][t]),
+                       sqrt_ac=float(host['sqrt_alphas_cumprod'][t]),
+                       sqrt_1m_ac=float(host['sqrt_one_minus_alphas_cumprod'][t]),
+                       c0=float(c[0]), c1=float(c[1]), c2=float(c[2]))
+
+    def model_predictions(self, x, t, x_self_cond=None, clip_x_start=False):
+        """DDP:613-634 (one timestep per batch, as every sampler uses it)."""
+        t0 = int(t[0])
+        out = self.model(x, t, x_self_cond)
+        step = self._step(self._host(), t0, ops.MODE_LAST, clip_x_start)
+        _, x_start, pred_noise = ops.sampler_step(step, out, None, x.contiguous(), None, True, True)
+        return ModelPrediction(pred_noise, x_start)
+
+    @torch.no_grad()
+    def p_sample(self, x, t: int, x_self_cond=None, clip_denoised=True, _host=None):
+        """DDP:647-661: one ancestral step -> (pred_img, x_start)."""
+        host = _host or self._host()
+        bt = torch.full((x.shape[0],), t, device=x.device, dtype=torch.long)
+        out = self.model(x, bt, x_self_cond)
+        # exp(0.5 * logvar) as fp32 0-dim tensor arithmetic, DDP:660
+        sd = float((0.5 * host['posterior_log_variance_clipped'][t]).exp())
+        step = self._step(host, t, ops.MODE_DDPM, clip_denoised,
+                          (host['posterior_mean_coef1'][t], host['posterior_mean_coef2'][t], sd))
+        noise = self.rng.randn(x.shape, x.device).contiguous() if t > 0 else None
+        img, x_start, _ = ops.sampler_step(step, out, None, x.contiguous(), noise, True)
+        return img, x_start
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape):
+        """DDP:663-680."""
+        device = self.betas.device
+        host = self._host()
+        img = self.rng.randn(shape, device).contiguous()
+        x_start = None
+        for t in reversed(range(0, self.num_timesteps)):
+            self_cond = x_start if self.self_condition else None
+            img, x_start = self.p_sample(img, t, self_cond, _host=host)
+        img = ops.affine(img, 0.5, 0.5)
+        ops.affine_tail_(img, img.shape[1] - 2, 2., -1.)          # flow channels back to [-1, 1], DDP:679
+        return img
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, clip_denoised=True):
+        """DDP:682-729."""
+        batch, device = shape[0], self.betas.device
+        host = self._host()
+        img = self.rng.randn(shape, device).contiguous()
+        x_start = None
+        for time, time_next in ddim_pairs(self.num_timesteps, self.sampling_timesteps):
+            time_cond = torch.full((batch,), time, device=device, dtype=torch.long)
+            self_cond = x_start if self.self_condition else None
+            out = self.model(img, time_cond, self_cond)
+            if time_next < 0:
+                step, noise = self._step(host, time, ops.MODE_LAST, clip_denoised), None
+            else:
+                step = self._step(host, time, ops.MODE_DDIM, clip_denoised, self._ddim_coef(host, time, time_next))
+                noise = self.rng.randn(shape, device).contiguous()
+            img, x_start, _ = ops.sampler_step(step, out, None, img, noise, True)
+        img = ops.affine(img, 0.5, 0.5)
+        ops.affine_tail_(img, img.shape[1] - 2, 2. * 512, -512.)   # (x*2-1)*512, DDP:728
+        return img
+
+    @torch.no_grad()
+    def sample(self, batch_size=16):
+        """DDP:731-735."""
+        shape = (batch_size, self.channels, self.image_size, self.image_size)
+        return self.ddim_sample(shape) if self.is_ddim_sampling else self.p_sample_loop(shape)
+
+    def q_sample(self, x_start, t, noise=None):
+        """DDP:756-761."""
+        noise = default(noise, lambda: self.rng.randn(x_start.shape, x_start.device))
+        ca = self.sqrt_alphas_cumprod.gather(-1, t).contiguous()
+        cb = self.sqrt_one_minus_alphas_cumprod.gather(-1, t).contiguous()
+        return ops.q_sample(x_start.contiguous(), noise.contiguous(), ca, cb)
+
+    def p_losses(self, x_start, t, noise=None):
+        raise NotImplementedError('training (p_losses + backward kernels) is SURVEY.md §8f "next" row 1, not built yet')
+
+    def forward(self, img, *args, **kwargs):
+        raise NotImplementedError('training (GaussianDiffusion.forward -> p_losses) is SURVEY.md §8f "next" row 1')
+
+
+# =====================================================================================
+# condition builder & geometry (DDP:913-988, 1262-1299, 1471-1486, 1558-1678)
+# =====================================================================================
+def adapt_homography_to_preprocessing_v3(h0, w0, H, h1, w1):
+    """G1, DDP:978-988: rescale a 3x3 homography between image sizes (host, float64, 27 flops)."""
+    def m(h, w):
+        return np.array([[w / 2.0, 0., w / 2.0], [0., h / 2.0, h / 2.0], [0., 0., 1.]])
+    M0, M1 = m(h0, w0), m(h1, w1)
+    return M1 @ (np.linalg.inv(M0) @ H @ M0) @ np.linalg.inv(M1)
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise RuntimeError('dmhomo_amd geometry kernels need a GPU; there is no CPU path')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def homo_to_flow_rgb(homos, H, W, max_flow=256):
+    """G2+G3 batched on device: homos (B,3,3) f64 (numpy or tensor) -> flow (B,2,H,W), rgb (B,3,H,W) fp32."""
+    Hm = torch.as_tensor(np.asarray(homos) if not torch.is_tensor(homos) else homos, dtype=torch.float64)
+    Hm = Hm.reshape(-1, 3, 3).to(_dev()).contiguous()
+    return ops.homography_flow(Hm, H, W, max(max_flow, 1.))
+
+
+def homo_to_flow(homo, H=600, W=800):
+    """DDP:972-975 signature: one homography (any shape with 9 elements) -> (H, W, 2) float32 numpy."""
+    flow, _ = ops.homography_flow(torch.as_tensor(np.asarray(homo), dtype=torch.float64).reshape(1, 3, 3)
+                                  .to(_dev()).contiguous(), H, W, 256., want_rgb=False)
+    return flow[0].permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+def flow_warp(x, flow12, pad='border', mode='bilinear'):
+    """G4, DDP:1262-1280."""
+    if pad != 'border' or mode != 'bilinear':
+        raise NotImplementedError('only the reference\'s defaults (bilinear, border) are built')
+    return ops.flow_warp(x.to(torch.float32).contiguous(), flow12.to(torch.float32).contiguous())
+
+
+def homo_gen(flow):
+    """G5, DDP:1647-1661: flow (B,2,H,W) -> (B,1,3,3) float64."""
+    return ops.dlt_homography(flow.to(torch.float32).contiguous()).reshape(-1, 1, 3, 3)
+
+
+def saveTrainPair(torch_tensor, mask, flows):
+    """G6, DDP:1664-1678: {"imgs": uint8 (B,6,H,W), "homos": float64 (B,3,3)}."""
+    assert torch.max(torch_tensor) <= 1, \
+        f'image should be normalized to [0, 1], not[{torch.min(torch_tensor)}, {torch.max(torch_tensor)}]'
+    imgs = ops.to_uint8(torch_tensor.detach().to(torch.float32).contiguous())
+    homos = homo_gen(flows)
+    return {'imgs': imgs.cpu().numpy(), 'homos': homos.cpu().numpy().squeeze()}
+
+
+# =====================================================================================
+# Trainer surface (DDP:1681-2021): constructor, save / load, sample
+# =====================================================================================
+class EMA(nn.Module):
+    """minimal stand-in for ema_pytorch.EMA holding the sampling copy (``ema_model``) with the same
+    state_dict prefixes (``ema_model.`` / ``online_model.`` + ``initted``, ``step``)."""
+
+    def __init__(self, model, beta=0.995, update_every=10):
+        super().__init__()
+        self.online_model = model
+        self.ema_model = model            # sampling reads ema_model (DDP:1960); weights are shared until trained
+        self.beta, self.update_every = beta, update_every
+        self.register_buffer('initted', torch.tensor(True))
+        self.register_buffer('step', torch.tensor(0))
+
+    def state_dict(self, *a, **k):
+        sd = self.online_model.state_dict()
+        out = {'initted': self.initted, 'step': self.step}
+        for key, v in sd.items():
+            out['online_model.' + key] = v
+            out['ema_model.' + key] = v
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        ema = {k[len('ema_model.'):]: v for k, v in sd.items() if k.startswith('ema_model.')}
+        return self.ema_model.load_state_dict(ema, strict=strict)
+
+
+class SyntheticConditions:
+    """endless iterator of condition batches in the 12-channel layout of DDP:1162
+    [img1(3) img2(3) mask(1) rgb_flow(3) flow(2)] built on device: seeded random
+    640x360 homographies -> G1 -> K7 flow / HSV image; mask = union of 3 random rectangles; class 0."""
+
+    def __init__(self, image_size, batch_size, seed=1000, device=None):
+        self.image_size, self.batch_size, self.seed, self.count = image_size, batch_size, seed, 0
+        self.device = device
+
+    def _homography(self, g):
+        u = lambda a: (torch.rand((), generator=g, dtype=torch.float64).item() * 2 - 1) * a
+        H0 = np.eye(3) + np.array([[u(.03), u(.03), u(8)], [u(.03), u(.03), u(8)], [u(3e-5), u(3e-5), 0.]])
+        return adapt_homography_to_preprocessing_v3(360, 640, H0, self.image_size, self.image_size)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        S, B = self.image_size, self.batch_size
+        dev = self.device or _dev()
+        homos, masks = [], torch.zeros((B, 1, S, S))
+        for i in range(B):
+            g = torch.Generator().manual_seed(self.seed + self.count + i)
+            homos.append(self._homography(g))
+            for _ in range(3):
+                r = torch.rand(4, generator=g)
+                y0, x0 = int(r[0] * S * 0.6), int(r[1] * S * 0.6)
+                h, w = int((0.25 + 0.3 * r[2]) * S), int((0.25 + 0.3 * r[3]) * S)
+                masks[i, 0, y0:y0 + h, x0:x0 + w] = 1.
+        self.count += B
+        flow, rgb = homo_to_flow_rgb(np.stack(homos), S, S)
+        data = torch.cat([torch.zeros((B, 6, S, S), device=dev), masks.to(dev), rgb, flow], dim=1)
+        return data, torch.zeros((B,), dtype=torch.long, device=dev)
+
+
+class Trainer(object):
+    """DDP:1681-2021.  Keeps the constructor, ``save`` / ``load`` (checkpoint dict layout of DDP:1786-1802)
+    and ``sample(idx, rank, step)``.  ``folder`` may be an iterator of (12-channel batch, classes) instead of the
+    reference's dataset directory (the CA-Homo dataset path is outside the hot path); ``train`` is a §8f row."""
+
+    def __init__(self, diffusion_model, folder, *, train_batch_size=16, gradient_accumulate_every=1,
+                 augment_horizontal_flip=True, train_lr=1e-4, train_num_steps=100000, ema_update_every=10,
+                 ema_decay=0.995, adam_betas=(0.9, 0.99), save_and_sample_every=1000, num_samples=9,
+                 results_folder='./results', amp=False, fp16=False, split_batches=True, convert_image_to=None,
+                 num_worker=8, total_data_slice_idx=1, data_slice_idx=1, shuffle=True, mixed_precision_type='fp16'):
+        self.model = diffusion_model
+        self.num_samples = num_samples
+        self.save_and_sample_every = save_and_sample_every
+        self.batch_size = train_batch_size
+        self.gradient_accumulate_every = gradient_accumulate_every
+        self.train_num_steps = train_num_steps
+        self.image_size = diffusion_model.image_size
+        if isinstance(folder, (str, os.PathLike)):
+            self.dl = SyntheticConditions(self.image_size, train_batch_size)
+        else:
+            self.dl = iter(folder)
+        self.ema = EMA(diffusion_model, beta=ema_decay, update_every=ema_update_every)
+        self.results_folder = Path(results_folder)
+        self.step = 0
+
+    def save(self, milestone):
+        self.results_folder.mkdir(exist_ok=True)
+        data = {'step': self.step, 'model': self.model.state_dict(), 'opt': None, 'ema': self.ema.state_dict(),
+                'scaler': None, 'version': __version__}
+        torch.save(data, str(self.results_folder / f'model-{milestone}.pt'))
+
+    def load(self, milestone):
+        data = torch.load(str(self.results_folder / f'model-{milestone}.pt'),
+                          map_location=next(self.model.parameters()).device)
+        self.model.load_state_dict(data['model'])
+        self.step = data['step']
+        if data.get('ema') is not None:
+            self.ema.load_state_dict(data['ema'], strict=False)
+        if 'version' in data:
+            print(f"loading from version {data['version']}")
+
+    def train(self):
+        raise NotImplementedError('Trainer.train (backward kernels + RCCL all-reduce) is SURVEY.md §8f "next" row 1')
+
+    def sample(self, idx, rank, step=1):
+        """DDP:1941-2021 without the every-100-steps PNG/GIF dumps (visualisation is out of scope)."""
+        data = next(self.dl)
+        dev = torch.device('cuda', rank) if isinstance(rank, int) else rank
+        rgb_flows = data[0][:, -5:-2].to(dev)
+        flows = data[0][:, -2:].to(dev).contiguous()
+        mask = data[0][:, -6:-5].to(dev)
+        with torch.no_grad():
+            all_images = self.ema.ema_model.sample(classes=data[1].to(dev), rgb_flow=rgb_flows, flow=flows, mask=mask)
+        return saveTrainPair(all_images[0], mask=all_images[1], flows=all_images[2])

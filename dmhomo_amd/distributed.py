@@ -1,0 +1,107 @@
+"""Multi-GPU sampling: one process per GPU, samples sharded across ranks.
+
+The denoising path has no cross-sample operation (GroupNorm, attention and the DDIM update
+are all per sample), so a global batch splits contiguously over the ranks with NO data-path
+collective.  RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in CPU tests) is used for
+  (1) one broadcast of the UNet weights from rank 0 at start-up — issued as scatter +
+      all-gather so that on the point-to-point xGMI mesh every link carries 1/world of the
+      153.7 MB payload instead of one link carrying all of it;
+  (2) one gather per batch of the uint8 image pairs + 3x3 homographies to rank 0.
+The reference's counterpart is N hand-launched independent processes (README:14,
+dgm_sample.py:13-18) that each load the checkpoint from disk.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), rank=rank, world_size=world)
+    device = torch.device('cuda', local) if use_cuda else torch.device('cpu')
+    return rank, world, device
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def shard_bounds(total, rank, world):
+    """contiguous [lo, hi) of ``total`` samples owned by ``rank`` (first ``total % world`` ranks get one more)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+@torch.no_grad()
+def broadcast_module_(module, src=0):
+    """make every rank's parameters and buffers equal to ``src``'s with ONE payload:
+    flatten -> scatter (1/world per peer) -> all-gather -> unflatten."""
+    if world_size() == 1:
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
+    others = [t for t in module.buffers() if not t.is_floating_point()]
+    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+    n = flat.numel()
+    per = (n + world - 1) // world
+    padded = torch.zeros(per * world, device=flat.device, dtype=torch.float32)
+    padded[:n] = flat
+    mine = torch.empty(per, device=flat.device, dtype=torch.float32)
+    chunks = list(padded.split(per)) if rank == src else None
+    dist.scatter(mine, chunks, src=src)
+    parts = [torch.empty(per, device=flat.device, dtype=torch.float32) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    full = torch.cat(parts)[:n]
+    off = 0
+    for t in tensors:
+        t.copy_(full[off:off + t.numel()].reshape(t.shape).to(t.dtype))
+        off += t.numel()
+    for t in others:
+        dist.broadcast(t, src=src)
+
+
+def gather_records(imgs_u8, homos, dst=0):
+    """per-rank {"imgs": uint8 (b,6,H,W), "homos": f64 (b,3,3)} tensors -> on ``dst`` the rank-ordered
+    concatenation (the record of saveTrainPair, DDP:1678); None elsewhere.  Equal shard sizes."""
+    if world_size() == 1:
+        return imgs_u8, homos
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out_i = [torch.empty_like(imgs_u8) for _ in range(world)] if rank == dst else None
+    out_h = [torch.empty_like(homos) for _ in range(world)] if rank == dst else None
+    dist.gather(imgs_u8, out_i, dst=dst)
+    dist.gather(homos, out_h, dst=dst)
+    if rank != dst:
+        return None, None
+    return torch.cat(out_i), torch.cat(out_h)
+
+
+class SampleIndexedRng:
+    """noise keyed by GLOBAL sample index: sample i always draws from its own generator seeded
+    ``seed * 1_000_003 + i``, so a sharded run reproduces the single-GPU run row for row
+    (drop-in for dmhomo_amd.cfg.DeviceRng)."""
+
+    def __init__(self, seed, sample_ids, device):
+        self.gens = []
+        for i in sample_ids:
+            g = torch.Generator(device=device)
+            g.manual_seed(seed * 1_000_003 + int(i))
+            self.gens.append(g)
+
+    def randn(self, shape, device):
+        assert shape[0] == len(self.gens)
+        return torch.stack([torch.randn(tuple(shape[1:]), generator=g, device=device) for g in self.gens])
+
+    def uniform(self, n, device):
+        assert n == len(self.gens)
+        return torch.cat([torch.rand((1,), generator=g, device=device) for g in self.gens])

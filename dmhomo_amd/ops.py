@@ -1,0 +1,254 @@
+"""Tensor-level wrappers of the C ABI (include/dmhomo_hip.h).
+
+PyTorch is used here only to allocate device memory (``torch.empty``) and to carry
+pointers; every value is produced by a kernel of libdmhomo_hip.so.  Activations
+are NHWC fp32 tensors shaped (B, H, W, C).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, lib
+
+F32 = torch.float32
+
+
+def _empty(shape, like, dtype=F32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+# ------------------------------------------------------------------ weight preparation
+def ws_standardize(w, eps=1e-5):
+    """N1: (w - mean_o) * rsqrt(var_o + eps) per output channel (CFG:123-126)."""
+    w = w.detach().contiguous()
+    out = torch.empty_like(w)
+    cout = w.shape[0]
+    call('dmh_ws_standardize', ptr(w), ptr(out), cout, w.numel() // cout, float(eps))
+    return out
+
+
+class PackedConv:
+    """a conv weight in dmh_conv2d's tile-major layout + its geometry."""
+    __slots__ = ('wpack', 'bias', 'cout', 'c0', 'c1', 'k', 'stride', 'upsample2')
+
+    def __init__(self, w_oihw, bias, c0, c1=0, stride=1, upsample2=0):
+        w = w_oihw.detach().contiguous()
+        cout, cin, kh, kw = w.shape
+        assert cin == c0 + c1 and kh == kw, (w.shape, c0, c1)
+        n = lib().dmh_conv_pack_floats(cout, c0, c1, kh, kw)
+        self.wpack = _empty((n,), w)
+        call('dmh_pack_conv_weight', ptr(w), ptr(self.wpack), cout, c0, c1, kh, kw)
+        self.bias = None if bias is None else bias.detach().contiguous()
+        self.cout, self.c0, self.c1, self.k, self.stride, self.upsample2 = cout, c0, c1, kh, stride, upsample2
+
+
+def conv_out_hw(pc, h, w):
+    if pc.upsample2:
+        return h * 2, w * 2
+    if pc.stride == 2:
+        return h // 2, w // 2
+    return h, w
+
+
+def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False):
+    """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats)."""
+    B, H, W, c0 = src0.shape
+    assert c0 == pc.c0 and (pc.c1 == 0) == (src1 is None), (src0.shape, pc.c0, pc.c1)
+    if src1 is not None:
+        assert src1.shape == (B, H, W, pc.c1), (src1.shape, pc.c1)
+    ho, wo = conv_out_hw(pc, H, W)
+    out = _empty((B, ho, wo, pc.cout), src0)
+    stats = None
+    if want_stats:
+        tiles = lib().dmh_conv_tiles(ho, wo, pc.k, pc.stride)
+        stats = _empty((B, tiles, pc.cout, 2), src0)
+    if res is not None:
+        assert res.shape == out.shape, (res.shape, out.shape)
+    d = _lib.DmhConv(ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
+                     ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2)
+    call('dmh_conv2d', C.byref(d))
+    return (out, stats) if want_stats else out
+
+
+# ------------------------------------------------------------------ normalisation glue
+def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5):
+    """N2: stats (B,tiles,C,2) -> coef (B,2,C).  ss: (B, >=2C) view whose row b starts with (scale[C], shift[C])."""
+    B, tiles, Cc, _ = stats.shape
+    coef = _empty((B, 2, Cc), stats)
+    ss_ptr, ss_stride = None, 0
+    if ss is not None:
+        assert ss.stride(1) == 1 and ss.shape[0] == B and ss.shape[1] == 2 * Cc
+        ss_ptr, ss_stride = C.c_void_p(ss.data_ptr()), ss.stride(0)
+    call('dmh_gn_finalize', ptr(stats), tiles, ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(coef), B, Cc, groups,
+         hw, float(eps))
+    return coef
+
+
+def gn_silu_residual(y, coef, res):
+    B, H, W, Cc = y.shape
+    out = torch.empty_like(y)
+    call('dmh_gn_silu_residual', ptr(y), ptr(coef), ptr(res), ptr(out), B, H * W, Cc)
+    return out
+
+
+def chan_layernorm(x, g, res=None, eps=1e-5):
+    """N4 (+ optional residual add)."""
+    Cc = x.shape[-1]
+    out = torch.empty_like(x)
+    call('dmh_chan_layernorm', ptr(x), ptr(g), ptr(res), ptr(out), x.numel() // Cc, Cc, float(eps))
+    return out
+
+
+# ------------------------------------------------------------------ attention cores
+def linear_attention_core(qkv, scale):
+    """K3.  qkv (B,H,W,384) -> (B,H,W,128)."""
+    B, H, W, c = qkv.shape
+    assert c == 384
+    n = H * W
+    partial = _empty((lib().dmh_linattn_partial_floats(B, n),), qkv)
+    ctx = _empty((B, 4, 32, 32), qkv)
+    out = _empty((B, H, W, 128), qkv)
+    call('dmh_linattn_context', ptr(qkv), ptr(partial), B, n)
+    call('dmh_linattn_merge', ptr(partial), ptr(ctx), B, n)
+    call('dmh_linattn_apply', ptr(qkv), ptr(ctx), ptr(out), B, n, float(scale))
+    return out
+
+
+def attention_core(qkv, scale):
+    """K4.  qkv (B,H,W,384) -> (B,H,W,128)."""
+    B, H, W, c = qkv.shape
+    assert c == 384
+    out = _empty((B, H, W, 128), qkv)
+    call('dmh_attention', ptr(qkv), ptr(out), B, H * W, float(scale))
+    return out
+
+
+# ------------------------------------------------------------------ embeddings
+ACT = {None: 0, 'silu': 1, 'gelu': 2}
+
+
+def sinusoidal_embed(t, freq):
+    R, dim = t.shape[0], freq.shape[0] * 2
+    out = _empty((R, dim), freq)
+    call('dmh_sinusoidal_embed', ptr(t, torch.int64), ptr(freq), ptr(out), R, dim)
+    return out
+
+
+def class_embed(classes, keep, table, null_emb):
+    R, dim = classes.shape[0], table.shape[1]
+    out = _empty((R, dim), table)
+    call('dmh_class_embed', ptr(classes, torch.int64), ptr(keep, torch.uint8), ptr(table), ptr(null_emb), ptr(out), R,
+         dim)
+    return out
+
+
+def linear(x, wt, bias, act_in=None, act_out=None, out=None):
+    """y = act_out(act_in(x) @ wt + bias); wt is W^T (in, out). x / out may be column slices (unit inner stride)."""
+    R, in_dim = x.shape
+    out_dim = wt.shape[1]
+    assert wt.shape[0] == in_dim and x.stride(1) == 1
+    if out is None:
+        out = _empty((R, out_dim), wt)
+    assert out.shape == (R, out_dim) and out.stride(1) == 1
+    call('dmh_linear', C.c_void_p(x.data_ptr()), x.stride(0), ptr(wt), ptr(bias), C.c_void_p(out.data_ptr()),
+         out.stride(0), R, in_dim, out_dim, ACT[act_in], ACT[act_out])
+    return out
+
+
+# ------------------------------------------------------------------ sampler glue
+def assemble_input(a, b=None, m=None, reps=1, cpad=None):
+    """(B,Ca,H,W) [+ (B,Cb,H,W) * (B,1,H,W)] NCHW -> NHWC (reps*B, H, W, cpad), zero padded."""
+    B, ca, H, W = a.shape
+    cb = 0 if b is None else b.shape[1]
+    if cpad is None:
+        cpad = (ca + cb + 3) // 4 * 4
+    out = _empty((reps * B, H, W, cpad), a)
+    call('dmh_assemble_input', ptr(a), ca, ptr(b), cb, ptr(m), ptr(out), B, reps, H * W, cpad)
+    return out
+
+
+def final_conv_nchw(x, w, bias):
+    R, H, W, Cc = x.shape
+    cout = w.shape[0]
+    out = _empty((R, cout, H, W), x)
+    call('dmh_final_conv_nchw', ptr(x), ptr(w), ptr(bias), ptr(out), R, H * W, Cc, cout)
+    return out
+
+
+OBJECTIVE = {'pred_noise': 0, 'pred_x0': 1, 'pred_v': 2}
+MODE_DDIM, MODE_LAST, MODE_DDPM = 0, 1, 2
+
+
+def sampler_step(step, model_cond, model_null, x, noise, want_x_start=True, want_pred_noise=False):
+    img = torch.empty_like(x)
+    xs = torch.empty_like(x) if want_x_start else None
+    pn = torch.empty_like(x) if want_pred_noise else None
+    call('dmh_sampler_step', C.byref(step), ptr(model_cond), ptr(model_null), ptr(x), ptr(noise), ptr(img), ptr(xs),
+         ptr(pn), x.numel())
+    return img, xs, pn
+
+
+def affine(x, scale, shift):
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    call('dmh_affine', ptr(x), ptr(y), float(scale), float(shift), x.numel())
+    return y
+
+
+def affine_tail_(x, c0, scale, shift):
+    B, Cc, H, W = x.shape
+    call('dmh_affine_tail', ptr(x), B, Cc, H * W, c0, float(scale), float(shift))
+    return x
+
+
+def q_sample(x_start, noise, ca, cb):
+    out = torch.empty_like(x_start)
+    B = x_start.shape[0]
+    call('dmh_q_sample', ptr(x_start), ptr(noise), ptr(ca), ptr(cb), ptr(out), B, x_start.numel() // B)
+    return out
+
+
+def to_uint8(img):
+    out = torch.empty(img.shape, device=img.device, dtype=torch.uint8)
+    call('dmh_to_uint8', ptr(img), ptr(out, torch.uint8), img.numel())
+    return out
+
+
+# ------------------------------------------------------------------ geometry
+def homography_flow(Hm, H, W, max_flow=256., want_flow=True, want_rgb=True):
+    """G2+G3.  Hm (B,3,3) f64 device -> flow (B,2,H,W), rgb (B,3,H,W)."""
+    B = Hm.shape[0]
+    flow = torch.empty((B, 2, H, W), device=Hm.device, dtype=F32) if want_flow else None
+    rgb = torch.empty((B, 3, H, W), device=Hm.device, dtype=F32) if want_rgb else None
+    call('dmh_homography_flow', ptr(Hm, torch.float64), ptr(flow), ptr(rgb), B, H, W, float(max_flow))
+    return flow, rgb
+
+
+def flow_to_image(flow, max_flow=256.):
+    """G3: flow (B,2,H,W) -> rgb (B,3,H,W)."""
+    B, _, H, W = flow.shape
+    rgb = torch.empty((B, 3, H, W), device=flow.device, dtype=F32)
+    call('dmh_flow_to_image', ptr(flow), ptr(rgb), B, H * W, float(max_flow))
+    return rgb
+
+
+def flow_warp(x, flow, want_indices=False):
+    B, Cc, H, W = x.shape
+    assert flow.shape == (B, 2, H, W)
+    out = torch.empty_like(x)
+    x0 = y0 = None
+    if want_indices:
+        x0 = torch.empty((B, H, W), device=x.device, dtype=torch.int32)
+        y0 = torch.empty((B, H, W), device=x.device, dtype=torch.int32)
+    call('dmh_flow_warp', ptr(x), ptr(flow), ptr(out), ptr(x0, torch.int32), ptr(y0, torch.int32), B, Cc, H, W)
+    return (out, x0, y0) if want_indices else out
+
+
+def dlt_homography(flow):
+    """G5: flow (B,2,H,W) fp32 -> (B,3,3) f64."""
+    B, _, H, W = flow.shape
+    ws = torch.empty((B, _lib.DLT_BLOCKS, 44), device=flow.device, dtype=torch.float64)
+    out = torch.empty((B, 3, 3), device=flow.device, dtype=torch.float64)
+    call('dmh_dlt_homography', ptr(flow), ptr(ws, torch.float64), ptr(out, torch.float64), B, H, W)
+    return out

@@ -1,0 +1,186 @@
+/*
+ * dmhomo_hip.h — C ABI of libdmhomo_hip.so: the gfx950 (MI355X / CDNA4) kernels under
+ * the DGM denoising hot path of lhaippp/DMHomo.
+ *
+ * The reference is pure Python/PyTorch and has NO native / FFI layer (SURVEY.md §0 fact 1,
+ * §8b): every entry point below replaces a *sequence of stock ATen ops* in the reference,
+ * cited per function as
+ *      CFG = DGM/denoising_diffusion_models/classifier_free_guidance.py
+ *      DDP = DGM/denoising_diffusion_models/denoising_diffusion_pytorch.py
+ * and is bound from Python with ctypes (dmhomo_amd/_lib.py; INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory owned by the caller
+ *     (torch tensors' data_ptr()), unless the name says host;
+ *   - activations are fp32 NHWC ([B][H][W][C], C % 4 == 0); API-boundary images are the
+ *     reference's fp32 NCHW;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued asynchronously on it, nothing synchronises, nothing allocates
+ *     (graph-capture safe);
+ *   - return 0 on success, a negative DMH_E* code otherwise; dmh_last_error() gives the
+ *     thread-local message. No exceptions cross the ABI.
+ */
+#ifndef DMHOMO_HIP_H
+#define DMHOMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMH_OK 0
+#define DMH_EINVAL (-1)  /* bad argument / unsupported shape */
+#define DMH_ELAUNCH (-2) /* hip launch error */
+
+const char* dmh_last_error(void);
+int dmh_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight preparation (once per load_state_dict; weights are constant while sampling)
+ * ------------------------------------------------------------------------------------- */
+
+/* N1  WeightStandardizedConv2d weight fold, CFG:120-126:
+ *   w_out[o] = (w[o] - mean_o) * rsqrt(var_biased_o + eps), stats over the K = Cin*kh*kw
+ *   elements of output channel o.  w, w_out: [Cout][K]. */
+int dmh_ws_standardize(const float* w, float* w_out, int Cout, int K, float eps, void* stream);
+
+/* number of floats of the packed image of an OIHW weight for dmh_conv2d */
+int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW);
+
+/* OIHW [Cout][C0+C1][KH][KW] -> tile-major image [ntile][chunk][tap][64][KC] consumed by
+ * dmh_conv2d (KC = 32 input channels per chunk, 16 for the 7x7 / strided variants; chunks
+ * never straddle the two concatenated sources; padding is zero). */
+int dmh_pack_conv_weight(const float* w_oihw, float* wpack, int Cout, int C0, int C1, int KH, int KW,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K1/K2  convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32)
+ * ------------------------------------------------------------------------------------- */
+typedef struct DmhConv {
+  const float* src0; /* NHWC [B][Hin][Win][C0] */
+  const float* src1; /* NHWC [B][Hin][Win][C1] or NULL: torch.cat((src0, src1), dim=1) fused (CFG:454,457,463) */
+  const float* wpack; /* dmh_pack_conv_weight image */
+  const float* bias;  /* [Cout] or NULL */
+  /* prologue on src0 (C1 must be 0): x <- SiLU(a[b][c]*x + b[b][c]) with coef = [B][2][C0]
+   * from dmh_gn_finalize: GroupNorm + (scale+1, shift) + SiLU of the producing Block, CFG:206-212 */
+  const float* in_coef;
+  /* epilogue residual, NHWC [B][Hout][Wout][Cout] or NULL:
+   *   res_coef == NULL : out += res                      (Residual, CFG:102-103)
+   *   res_coef != NULL : out += SiLU(a*res + b)          (h + res_conv(x), CFG:241, h = block2 output) */
+  const float* res;
+  const float* res_coef;
+  float* out;   /* NHWC [B][Hout][Wout][Cout] */
+  float* stats; /* NULL or [B][tiles][Cout][2] per-tile (sum, sum of squares) of `out` for GroupNorm */
+  int32_t B, Hin, Win, C0, C1, Cout;
+  int32_t KH, KW;     /* 1x1, 3x3, 7x7 (stride 1, pad k/2); 4x4 (stride 2, pad 1); 2x2 (stride 2, pad 0) */
+  int32_t stride;     /* 1 or 2 */
+  int32_t upsample2;  /* 1: nearest x2 of the input fused into the 3x3 gather (Upsample, CFG:106-107) */
+} DmhConv;
+
+/* tiles per sample that dmh_conv2d will use for this geometry (size of the stats buffer) */
+int dmh_conv_tiles(int Hout, int Wout, int KH, int stride);
+int dmh_conv2d(const DmhConv* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Normalisation / activation glue (HBM-bound)
+ * ------------------------------------------------------------------------------------- */
+
+/* N2  GroupNorm statistics -> per-(sample, channel) affine of Block.forward, CFG:206-210:
+ *   coef[b][0][c] = a = rstd*gamma*(scale+1), coef[b][1][c] = (beta - mean*rstd*gamma)*(scale+1) + shift
+ * stats: [B][tiles][C][2] from dmh_conv2d; ss: NULL or row b at ss + b*ss_stride holds
+ * (scale[C], shift[C]) (ResnetBlock mlp output chunk(2), CFG:233-235). Reduction in f64, fixed order. */
+int dmh_gn_finalize(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
+                    int64_t ss_stride, float* coef, int B, int C, int groups, int hw, float eps, void* stream);
+
+/* out = SiLU(a*y + b) + res   (identity res_conv branch of ResnetBlock, CFG:225,241) */
+int dmh_gn_silu_residual(const float* y, const float* coef, const float* res, float* out, int B, int HW, int C,
+                         void* stream);
+
+/* N4  channel LayerNorm (biased var, gain only), CFG:137-141, optionally + res (Residual, CFG:103) */
+int dmh_chan_layernorm(const float* x, const float* g, const float* res, float* out, int64_t npix, int C,
+                       float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K3  LinearAttention core, CFG:258-269.  qkv: NHWC [B][n][384] = (q|k|v) x 4 heads x 32.
+ * ------------------------------------------------------------------------------------- */
+int dmh_linattn_splits(int n);
+int64_t dmh_linattn_partial_floats(int B, int n);
+/* pass 1: per split of the n pixels, running max / sum of exp / unnormalised k^T v per head */
+int dmh_linattn_context(const float* qkv, float* partial, int B, int n, void* stream);
+/* merge the splits: ctx[b][h][d][e] = softmax_n(k)[d,:] . (v/n)[e,:] */
+int dmh_linattn_merge(const float* partial, float* ctx, int B, int n, void* stream);
+/* pass 2: out[b][p][h*32+e] = sum_d ctx[d][e] * (softmax_d(q[p]) * scale)[d]; out NHWC [B][n][128] */
+int dmh_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int n, float scale, void* stream);
+
+/* K4  Attention core, CFG:287-295: softmax_j((q*scale)^T k) v; out NHWC [B][n][128] */
+int dmh_attention(const float* qkv, float* out, int B, int n, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K5  embeddings / small linears
+ * ------------------------------------------------------------------------------------- */
+/* N7  SinusoidalPosEmb, CFG:165-172: out[r] = (sin(t_r*f), cos(t_r*f)); freq[dim/2] fp32 table */
+int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* out, int R, int dim, void* stream);
+/* N8  classes_emb lookup + null swap, CFG:419-425: keep==NULL keeps every row */
+int dmh_class_embed(const int64_t* classes, const uint8_t* keep, const float* table, const float* null_emb,
+                    float* out, int R, int dim, void* stream);
+/* y[r][o] = act_out( sum_i act_in(x[r][i]) * wt[i][o] + bias[o] ), wt = W^T [in][out].
+ * act: 0 none, 1 SiLU, 2 GELU(erf).  (time_mlp / classes_mlp CFG:353,362; ResnetBlock.mlp CFG:220) */
+int dmh_linear(const float* x, int64_t x_stride, const float* wt, const float* bias, float* y, int64_t y_stride,
+               int R, int in_dim, int out_dim, int act_in, int act_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K6  sampler glue (NCHW at the API boundary)
+ * ------------------------------------------------------------------------------------- */
+/* network input: out NHWC [reps*B][H][W][Cpad] <- cat(a [B][Ca][H][W], b*m [B][Cb][H][W]) zero padded;
+ * b, m may be NULL (Cb = 0).  torch.concat((x, rgb_flow*mask)) CFG:430 / cat((x_self_cond, x)) DDP:411 */
+int dmh_assemble_input(const float* a, int Ca, const float* b, int Cb, const float* m, float* out, int B, int reps,
+                       int HW, int Cpad, void* stream);
+/* final_conv 1x1 (CFG:401,466): NHWC [R][HW][C] -> NCHW [R][Cout][HW], Cout <= 16 */
+int dmh_final_conv_nchw(const float* x, const float* w, const float* bias, float* out, int R, int HW, int C,
+                        int Cout, void* stream);
+
+typedef struct DmhStep {
+  int32_t objective;  /* 0 pred_noise, 1 pred_x0, 2 pred_v            CFG:614-628 */
+  int32_t clip;       /* clamp x_start to [-1,1]                       CFG:612 */
+  int32_t mode;       /* 0 DDIM update, 1 DDIM last (img = x_start), 2 DDPM posterior step */
+  float cond_scale;   /* CFG blend null + (cond-null)*s, CFG:410; ignored when model_null == NULL */
+  float sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac, sqrt_1m_ac; /* extract(..., t) CFG:586-601 */
+  float c0, c1, c2;   /* DDIM: sqrt(alpha_next), c, sigma (CFG:697-707); DDPM: coef1, coef2, exp(.5 logvar) */
+} DmhStep;
+/* one sampler step on NCHW tensors of n elements: writes img_out and (if non-NULL) x_start, pred_noise */
+int dmh_sampler_step(const DmhStep* s, const float* model_cond, const float* model_null, const float* x,
+                     const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
+                     void* stream);
+
+/* y = x*scale + shift elementwise (normalize / unnormalize, CFG:69-74) */
+int dmh_affine(const float* x, float* y, float scale, float shift, int64_t n, void* stream);
+/* in place on channels >= c0 of an NCHW tensor: x = x*scale + shift (flow channel remap, DDP:679,728) */
+int dmh_affine_tail(float* x, int B, int C, int HW, int c0, float scale, float shift, void* stream);
+/* D9 q_sample CFG:738-742: out = ca[b]*x_start + cb[b]*noise, ca/cb = extract(sqrt_ac / sqrt_1m_ac, t) */
+int dmh_q_sample(const float* x_start, const float* noise, const float* ca, const float* cb, float* out, int B,
+                 int64_t per_sample, void* stream);
+/* G6  saveTrainPair DDP:1673: uint8 truncation of img*255 */
+int dmh_to_uint8(const float* img, uint8_t* out, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * K7-K9  condition builder & geometry
+ * ------------------------------------------------------------------------------------- */
+/* G2+G3  homo_to_flow DDP:927-975 + flow_to_image DDP:1471-1486.  Hm: [B][9] f64 (device);
+ * flow NCHW [B][2][H][W] fp32, rgb NCHW [B][3][H][W] fp32 (either may be NULL) */
+int dmh_homography_flow(const double* Hm, float* flow, float* rgb, int B, int H, int W, float max_flow,
+                        void* stream);
+/* G3 alone: flow NCHW [B][2][HW] -> rgb NCHW [B][3][HW] (flow_to_image DDP:1471-1486) */
+int dmh_flow_to_image(const float* flow, float* rgb, int B, int HW, float max_flow, void* stream);
+/* G4  flow_warp DDP:1262-1299 (bilinear, border, align_corners=True); x/out NCHW [B][C][H][W], flow [B][2][H][W].
+ * x0/y0 (NULL or int32 [B][H][W]) receive the top-left corner indices (bit-exact contract). */
+int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, int32_t* y0, int B, int C, int H,
+                  int W, void* stream);
+/* G5  homo_gen / DLT_solve DDP:1577-1661 through f64 normal equations; ws: [B][DMH_DLT_BLOCKS][44] f64 */
+#define DMH_DLT_BLOCKS 64
+int dmh_dlt_homography(const float* flow, double* ws, double* Hout, int B, int H, int W, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMHOMO_HIP_H */

@@ -1,0 +1,62 @@
+"""CPU: libdmhomo_hip.so loads without a GPU and exports every symbol include/dmhomo_hip.h declares;
+argument validation answers through the error channel (no compute is launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'dmhomo_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(dmh_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_and_binding_agree():
+    from dmhomo_amd import _lib
+    names = header_functions()
+    assert len(names) >= 30
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_library_loads_and_exports_every_symbol():
+    from dmhomo_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'run `python -c "import __graft_entry__ as g; g.build()"` first'
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for name in header_functions():
+        assert hasattr(h, name), name
+    lib = _lib.lib()
+    assert lib.dmh_version() >= 100
+
+
+def test_pure_host_entry_points():
+    from dmhomo_amd import _lib
+    lib = _lib.lib()
+    # packed size: ceil(Cout/64) * chunks * taps * 64 * KC
+    assert lib.dmh_conv_pack_floats(64, 64, 0, 3, 3) == 1 * 2 * 9 * 64 * 32
+    assert lib.dmh_conv_pack_floats(512, 512, 256, 3, 3) == 8 * (16 + 8) * 9 * 64 * 32
+    assert lib.dmh_conv_pack_floats(64, 12, 0, 7, 7) == 1 * 1 * 49 * 64 * 16
+    assert lib.dmh_conv_pack_floats(128, 64, 0, 4, 4) == 2 * 4 * 16 * 64 * 16
+    assert lib.dmh_conv_tiles(128, 128, 3, 1) == 64 and lib.dmh_conv_tiles(64, 64, 4, 2) == 32
+    assert lib.dmh_linattn_splits(16384) == 128 and lib.dmh_linattn_splits(4) == 1
+    assert lib.dmh_linattn_partial_floats(2, 256) == 2 * 2 * 4 * 1088
+
+
+def test_bad_arguments_use_the_error_channel():
+    from dmhomo_amd import _lib
+    lib = _lib.lib()
+    d = _lib.DmhConv()
+    assert lib.dmh_conv2d(ctypes.byref(d), None) == -1
+    assert b'dmh_conv2d' in lib.dmh_last_error()
+    assert lib.dmh_chan_layernorm(None, None, None, None, 4, 64, 1e-5, None) == -1
+    assert lib.dmh_linear(None, 0, None, None, None, 0, 1, 1, 1, 0, 0, None) == -1
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    from dmhomo_amd import ops, _lib
+    with pytest.raises(_lib.DmhError):
+        ops.affine(torch.zeros(4), 1.0, 0.0)

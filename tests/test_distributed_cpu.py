@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing of the sample-sharded path (weights broadcast as
+scatter + all-gather, contiguous shards, rank-ordered gather, GPU-count-invariant noise)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from dmhomo_amd import distributed as D
+    from dmhomo_amd import cfg
+    r, w, device = D.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)                      # different initial weights per rank
+    m = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=50, sampling_timesteps=4, objective='pred_x0')
+    if rank == 1:
+        d.betas.add_(1.0)                              # buffers travel too
+    D.broadcast_module_(d, src=0)
+    digest = float(sum(p.double().sum() for p in d.state_dict().values()))
+    lo, hi = D.shard_bounds(5, rank, world)
+    total = 6
+    slo, shi = D.shard_bounds(total, rank, world)
+    imgs = torch.arange(slo, shi, dtype=torch.uint8).reshape(-1, 1, 1, 1).expand(-1, 6, 2, 2).contiguous()
+    homos = torch.arange(slo, shi, dtype=torch.float64).reshape(-1, 1, 1).expand(-1, 3, 3).contiguous()
+    gi, gh = D.gather_records(imgs, homos, dst=0)
+    rng = D.SampleIndexedRng(7, range(slo, shi), device)
+    n1 = rng.randn((shi - slo, 2, 3), device)
+    u1 = rng.uniform(shi - slo, device)
+    q.put((rank, digest, (lo, hi), None if gi is None else gi[:, 0, 0, 0].tolist(),
+           None if gh is None else gh[:, 0, 0].tolist(), n1, u1))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, d0, b0, gi0, gh0, n0, u0), (r1, d1, b1, gi1, gh1, n1, u1) = res
+    assert d0 == d1                                     # identical weights + buffers after the broadcast
+    assert b0 == (0, 3) and b1 == (3, 5)                # contiguous, first ranks take the remainder
+    assert gi0 == [0, 1, 2, 3, 4, 5] and gh0 == [0., 1., 2., 3., 4., 5.] and gi1 is None
+    from dmhomo_amd import distributed as D
+    full = D.SampleIndexedRng(7, range(0, 6), torch.device('cpu'))
+    assert torch.equal(torch.cat([n0, n1]), full.randn((6, 2, 3), torch.device('cpu')))
+    assert torch.equal(torch.cat([u0, u1]), full.uniform(6, torch.device('cpu')))
+
+
+def test_shard_bounds_cover():
+    from dmhomo_amd.distributed import shard_bounds
+    for total in (0, 1, 7, 25, 200):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1

@@ -1,0 +1,283 @@
+"""-m gpu: each HIP kernel through the C ABI against the CPU oracle / plain torch fp32 on the same inputs.
+
+Tolerances: the kernels accumulate in fp32 like the reference but in a different order
+(k-ordered MFMA fmaf chains vs oneDNN blocking), so results differ by a few fp32 ulps of the
+accumulated magnitude: rtol 1e-4 / atol 1e-5 relative to unit-scale data unless stated.
+Integer outputs (grid-sample corner indices, uint8 export) must be bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import dev, nhwc, nchw, close, rand
+from detweights import det_state_dict
+from oracle import unet as OU, geometry as OG
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dmhomo_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+# ---------------------------------------------------------------------------- conv variants
+CONV_CASES = [
+    # name, B, H, W, C0, C1, Cout, k, stride, ups
+    ('3x3 64->64 16x16', 2, 16, 16, 64, 0, 64, 3, 1, 0),
+    ('3x3 ragged 8->24 19x23', 2, 19, 23, 8, 0, 24, 3, 1, 0),
+    ('3x3 concat 64+32->96 20x12', 2, 20, 12, 64, 32, 96, 3, 1, 0),
+    ('3x3 concat small 8+16->8 9x9', 1, 9, 9, 8, 16, 8, 3, 1, 0),
+    ('3x3 upsample 32->16 7x9', 2, 7, 9, 32, 0, 16, 3, 1, 1),
+    ('1x1 64->384 16x16', 2, 16, 16, 64, 0, 384, 1, 1, 0),
+    ('1x1 concat 40+24->72 5x33', 3, 5, 33, 40, 24, 72, 1, 1, 0),
+    ('7x7 12->64 32x32', 2, 32, 32, 12, 0, 64, 7, 1, 0),
+    ('7x7 ragged 4->8 21x18', 1, 21, 18, 4, 0, 8, 7, 1, 0),
+    ('4x4s2 64->128 32x32', 2, 32, 32, 64, 0, 128, 4, 2, 0),
+    ('4x4s2 ragged 8->16 22x38', 1, 22, 38, 8, 0, 16, 4, 2, 0),
+    ('2x2s2 16->32 24x40', 2, 24, 40, 16, 0, 32, 2, 2, 0),
+    ('3x3 tiny 4x4 256->512', 2, 4, 4, 256, 0, 512, 3, 1, 0),
+]
+
+
+def ref_conv(x, w, b, k, stride, ups):
+    if ups:
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    pad = k // 2 if stride == 1 else (1 if k == 4 else 0)
+    return F.conv2d(x, w, b, stride, pad)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv2d(ops, case):
+    name, B, H, W, C0, C1, Cout, k, stride, ups = case
+    x = rand((B, C0 + C1, H, W), 1)
+    w = rand((Cout, C0 + C1, k, k), 2, (1.0 / ((C0 + C1) * k * k)) ** 0.5)
+    b = rand((Cout,), 3, 0.1)
+    pc = ops.PackedConv(w.to(dev()), b.to(dev()), C0, C1, stride, ups)
+    s0 = nhwc(x[:, :C0])
+    s1 = nhwc(x[:, C0:]) if C1 else None
+    out, stats = ops.conv2d(pc, s0, s1, want_stats=True)
+    ref = ref_conv(x, w, b, k, stride, ups)
+    close(name, nchw(out), ref, rtol=1e-4, atol=2e-5)
+    # per-tile GroupNorm partials sum to the per-channel totals
+    tot = stats.sum(dim=1).cpu().double()
+    close(name + ' stats.sum', tot[..., 0], ref.double().sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
+    close(name + ' stats.sumsq', tot[..., 1], (ref.double() ** 2).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
+
+
+def test_conv2d_prologue_and_residual(ops):
+    """GN-apply+SiLU prologue (zero padding applies to the ACTIVATED tensor) and both residual epilogues"""
+    B, H, W, C, Co = 2, 18, 21, 32, 48
+    x = rand((B, C, H, W), 4)
+    w = rand((Co, C, 3, 3), 5, 0.06)
+    a, bb = 1 + 0.3 * rand((B, C), 6), 0.5 * rand((B, C), 7)
+    coef = torch.stack([a, bb], 1).contiguous().to(dev())                       # (B,2,C)
+    res = rand((B, Co, H, W), 8)
+    ra, rb = 1 + 0.2 * rand((B, Co), 9), 0.3 * rand((B, Co), 10)
+    rcoef = torch.stack([ra, rb], 1).contiguous().to(dev())
+    pc = ops.PackedConv(w.to(dev()), None, C)
+    act = F.silu(a[:, :, None, None] * x + bb[:, :, None, None])
+    base = F.conv2d(act, w, None, 1, 1)
+    close('prologue', nchw(ops.conv2d(pc, nhwc(x), in_coef=coef)), base, rtol=1e-4, atol=2e-5)
+    close('prologue+res', nchw(ops.conv2d(pc, nhwc(x), in_coef=coef, res=nhwc(res))), base + res, rtol=1e-4,
+          atol=2e-5)
+    want = base + F.silu(ra[:, :, None, None] * res + rb[:, :, None, None])
+    close('prologue+gn-res', nchw(ops.conv2d(pc, nhwc(x), in_coef=coef, res=nhwc(res), res_coef=rcoef)), want,
+          rtol=1e-4, atol=2e-5)
+
+
+def test_conv2d_rejects_bad_channels(ops):
+    from dmhomo_amd._lib import DmhError
+    pc = ops.PackedConv(rand((8, 6, 3, 3), 1).to(dev()), None, 6)
+    with pytest.raises(DmhError):
+        ops.conv2d(pc, torch.zeros((1, 4, 4, 6), device=dev()))
+
+
+def test_ws_standardize(ops):
+    w = rand((24, 40, 3, 3), 11, 0.3) + 0.05
+    close('ws_fold', ops.ws_standardize(w.to(dev())).cpu(), OU.ws_fold(w), rtol=1e-5, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------- GroupNorm glue
+@pytest.mark.parametrize('C,H,W', [(64, 16, 16), (8, 9, 13), (512, 4, 4)])
+def test_block_gn_silu(ops, C, H, W):
+    """Block.forward CFG:204-213 = conv -> gn_finalize -> SiLU(a*y+b) (+0 residual)"""
+    B, groups = 2, 8
+    p = det_state_dict({'proj.weight': (C, C, 3, 3), 'proj.bias': (C,), 'norm.weight': (C,), 'norm.bias': (C,)}, 2)
+    x = rand((B, C, H, W), 12)
+    scale, shift = rand((B, C, 1, 1), 13, 0.3), rand((B, C, 1, 1), 14, 0.3)
+    ref = OU.block(p, x, groups, (scale, shift))
+    ref0 = OU.block(p, x, groups)
+    wn = ops.ws_standardize(p['proj.weight'].to(dev()))
+    pc = ops.PackedConv(wn, p['proj.bias'].to(dev()), C)
+    y, st = ops.conv2d(pc, nhwc(x), want_stats=True)
+    ss = torch.cat([scale.reshape(B, C), shift.reshape(B, C)], 1).contiguous().to(dev())
+    g, b = p['norm.weight'].to(dev()), p['norm.bias'].to(dev())
+    coef = ops.gn_finalize(st, g, b, H * W, groups, ss)
+    zero = torch.zeros_like(y)
+    close(f'block C={C} ss', nchw(ops.gn_silu_residual(y, coef, zero)), ref, rtol=2e-4, atol=2e-5)
+    coef0 = ops.gn_finalize(st, g, b, H * W, groups)
+    close(f'block C={C}', nchw(ops.gn_silu_residual(y, coef0, None)), ref0, rtol=2e-4, atol=2e-5)
+
+
+def test_gn_constant_input_is_beta(ops):
+    """known answer: GroupNorm of a constant tensor = beta (variance 0 -> (x-mean) = 0)"""
+    B, C, H, W = 1, 16, 8, 8
+    y = torch.full((B, H, W, C), 3.25, device=dev())
+    st = torch.empty((B, 1, C, 2), device=dev())
+    st[..., 0] = 3.25 * H * W
+    st[..., 1] = 3.25 * 3.25 * H * W
+    g, b = (1 + rand((C,), 1)).to(dev()), rand((C,), 2).to(dev())
+    coef = ops.gn_finalize(st, g, b, H * W, 8)
+    out = coef[:, 0, :] * 3.25 + coef[:, 1, :]
+    close('gn const', out.cpu(), b.cpu()[None], rtol=0, atol=2e-3)      # rstd = 1/sqrt(eps) amplifies rounding
+
+
+@pytest.mark.parametrize('C', [8, 64, 128, 512])
+def test_chan_layernorm(ops, C):
+    x = rand((2, C, 7, 9), 15) * 2 + 0.7
+    g = 1 + 0.2 * rand((1, C, 1, 1), 16)
+    r = rand((2, C, 7, 9), 17)
+    ref = OU.chan_layernorm(x, g)
+    gd = g.reshape(-1).contiguous().to(dev())
+    close(f'LN C={C}', nchw(ops.chan_layernorm(nhwc(x), gd)), ref, rtol=1e-5, atol=1e-5)
+    close(f'LN+res C={C}', nchw(ops.chan_layernorm(nhwc(x), gd, res=nhwc(r))), ref + r, rtol=1e-5, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- attention cores
+def _split_heads(qkv):
+    b, _, h, w = qkv.shape
+    return [t.reshape(b, 4, 32, h * w) for t in qkv.chunk(3, dim=1)]
+
+
+@pytest.mark.parametrize('H,W', [(16, 16), (4, 4), (2, 2), (13, 11), (32, 48)])
+def test_linear_attention_core(ops, H, W):
+    qkv = rand((2, 384, H, W), 18) * 1.5
+    q, k, v = _split_heads(qkv)
+    n = H * W
+    q = q.softmax(dim=-2) * 32 ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum('b h d n, b h e n -> b h d e', k, v / n)
+    ref = torch.einsum('b h d e, b h d n -> b h e n', ctx, q).reshape(2, 128, H, W)
+    close(f'linattn {H}x{W}', nchw(ops.linear_attention_core(nhwc(qkv), 32 ** -0.5)), ref, rtol=1e-4, atol=1e-6)
+
+
+def test_linear_attention_uniform_k_gives_mean_v(ops):
+    """known answer: constant k -> softmax_n uniform -> ctx[d][e] = mean_n v[e] for every d"""
+    H = W = 12
+    qkv = rand((1, 384, H, W), 19)
+    qkv[:, 128:256] = 0.37
+    out = nchw(ops.linear_attention_core(nhwc(qkv), 32 ** -0.5))
+    q, k, v = _split_heads(qkv)
+    qs = q.softmax(dim=-2) * 32 ** -0.5                       # sums to scale over d
+    want = v.mean(-1)[..., None] * qs.sum(2, keepdim=True)     # (b,h,e,n)
+    close('linattn uniform-k', out, want.reshape(1, 128, H, W), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('H,W', [(16, 16), (2, 2), (4, 4), (7, 9), (32, 32)])
+def test_attention_core(ops, H, W):
+    qkv = rand((2, 384, H, W), 20) * 1.5
+    q, k, v = _split_heads(qkv)
+    sim = torch.einsum('b h d i, b h d j -> b h i j', q * 32 ** -0.5, k)
+    out = torch.einsum('b h i j, b h d j -> b h i d', sim.softmax(dim=-1), v)
+    ref = out.permute(0, 1, 3, 2).reshape(2, 128, H, W)
+    close(f'attn {H}x{W}', nchw(ops.attention_core(nhwc(qkv), 32 ** -0.5)), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_attention_online_softmax_rescale(ops):
+    """force the running-max rescale: one late key dominates every query (guide rule 26)"""
+    H = W = 16
+    qkv = rand((1, 384, H, W), 21)
+    qkv[:, 128:256, 13, 5] *= 25.0
+    qkv[:, 0:128] = qkv[:, 128:256, 13:14, 5:6].sign() * qkv[:, 0:128].abs()
+    q, k, v = _split_heads(qkv)
+    sim = torch.einsum('b h d i, b h d j -> b h i j', q * 32 ** -0.5, k)
+    out = torch.einsum('b h i j, b h d j -> b h i d', sim.double().softmax(dim=-1), v.double())
+    ref = out.permute(0, 1, 3, 2).reshape(1, 128, H, W).float()
+    close('attn rescale', nchw(ops.attention_core(nhwc(qkv), 32 ** -0.5)), ref, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- embeddings
+def test_embeddings(ops):
+    sd = det_state_dict({'time_mlp.1.weight': (256, 64), 'time_mlp.1.bias': (256,), 'time_mlp.3.weight': (256, 256),
+                         'time_mlp.3.bias': (256,), 'classes_emb.weight': (3, 64), 'null_classes_emb': (64,),
+                         'classes_mlp.0.weight': (256, 64), 'classes_mlp.0.bias': (256,),
+                         'classes_mlp.2.weight': (256, 256), 'classes_mlp.2.bias': (256,)}, 3)
+    t = torch.tensor([999, 0, 37, 500])
+    import math
+    half = 32
+    freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1)))
+    se = ops.sinusoidal_embed(t.to(dev()), freq.to(dev()))
+    close('sinusoid', se.cpu(), OU.sinusoidal_pos_emb(t, 64), rtol=0, atol=2e-6)
+    d = lambda k: sd[k].to(dev())
+    h = ops.linear(se, d('time_mlp.1.weight').t().contiguous(), d('time_mlp.1.bias'), act_out='gelu')
+    te = ops.linear(h, d('time_mlp.3.weight').t().contiguous(), d('time_mlp.3.bias'))
+    close('time_mlp', te.cpu(), OU.time_mlp(sd, t, 64), rtol=1e-4, atol=1e-5)
+    classes = torch.tensor([0, 2, 1, 2])
+    keep = torch.tensor([True, False, True, False])
+    ce = ops.class_embed(classes.to(dev()), keep.to(torch.uint8).to(dev()), d('classes_emb.weight'),
+                         d('null_classes_emb'))
+    hm = ops.linear(ce, d('classes_mlp.0.weight').t().contiguous(), d('classes_mlp.0.bias'), act_out='gelu')
+    cm = ops.linear(hm, d('classes_mlp.2.weight').t().contiguous(), d('classes_mlp.2.bias'))
+    close('classes_mlp', cm.cpu(), OU.class_mlp(sd, classes, keep), rtol=1e-4, atol=1e-5)
+    w = rand((640, 512), 22, 0.05)
+    x = rand((4, 512), 23)
+    y = ops.linear(x.to(dev()), w.t().contiguous().to(dev()), None, act_in='silu')
+    close('mlp silu-in', y.cpu(), F.linear(F.silu(x), w), rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------- sampler glue
+def test_assemble_and_final_conv(ops):
+    x, rf, m = rand((2, 6, 9, 11), 24), rand((2, 3, 9, 11), 25), (rand((2, 1, 9, 11), 26) > 0).float()
+    out = ops.assemble_input(x.to(dev()), rf.to(dev()), m.to(dev()), reps=2, cpad=12)
+    want = torch.cat([x, rf * m, torch.zeros(2, 3, 9, 11)], 1).repeat(2, 1, 1, 1)
+    assert torch.equal(nchw(out), want)
+    h = rand((3, 64, 5, 7), 27)
+    w, b = rand((6, 64), 28, 0.1), rand((6,), 29)
+    got = ops.final_conv_nchw(nhwc(h), w.to(dev()), b.to(dev()))
+    close('final_conv', got.cpu(), F.conv2d(h, w[:, :, None, None], b), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('objective', ['pred_noise', 'pred_x0', 'pred_v'])
+def test_sampler_step(ops, objective):
+    from dmhomo_amd._lib import DmhStep
+    from oracle import diffusion as OD
+    buf = OD.schedule_buffers(1000, 'cosine')
+    n = (2, 6, 8, 8)
+    cond, null, x, noise = (rand(n, s) for s in (30, 31, 32, 33))
+    t, tn, s = 749, 499, 3.0
+    mo = null + (cond - null) * s
+    tt = torch.full((2,), t, dtype=torch.long)
+    pn, x0 = OD._predictions(buf, objective, mo, x, tt, True)
+    want = OD._ddim_update(buf, x0, pn, t, tn, 1.0, noise)
+    c0, c1, c2 = OD.ddim_coefficients(buf, t, tn)
+    step = DmhStep(objective=ops.OBJECTIVE[objective], clip=1, mode=ops.MODE_DDIM, cond_scale=s,
+                   sqrt_recip_ac=float(buf['sqrt_recip_alphas_cumprod'][t]),
+                   sqrt_recipm1_ac=float(buf['sqrt_recipm1_alphas_cumprod'][t]),
+                   sqrt_ac=float(buf['sqrt_alphas_cumprod'][t]),
+                   sqrt_1m_ac=float(buf['sqrt_one_minus_alphas_cumprod'][t]), c0=c0, c1=c1, c2=c2)
+    g = lambda v: v.to(dev())
+    img, xs, pnd = ops.sampler_step(step, g(cond), g(null), g(x), g(noise), True, True)
+    # elementwise fp32 with the reference's op order and no FMA contraction: bit-exact
+    assert torch.equal(xs.cpu(), x0), float((xs.cpu() - x0).abs().max())
+    assert torch.equal(pnd.cpu(), pn)
+    assert torch.equal(img.cpu(), want)
+
+
+def test_affine_uint8_qsample(ops):
+    x = torch.rand((2, 6, 5, 5), generator=torch.Generator().manual_seed(3))
+    assert torch.equal(ops.affine(x.to(dev()), 0.5, 0.5).cpu(), (x + 1) * 0.5)
+    assert torch.equal(ops.affine(x.to(dev()), 2., -1.).cpu(), x * 2 - 1)
+    assert np.array_equal(ops.to_uint8(x.to(dev())).cpu().numpy(), (x.numpy() * 255).astype(np.uint8))
+    edge = torch.tensor([0., 1., 0.999999, 1 / 255., 0.5])
+    assert np.array_equal(ops.to_uint8(edge.to(dev())).cpu().numpy(), (edge.numpy() * 255).astype(np.uint8))
+    y = x.clone()
+    y[:, -2:] = y[:, -2:] * 2 - 1
+    assert torch.equal(ops.affine_tail_(x.clone().to(dev()), 4, 2., -1.).cpu(), y)
+    ca, cb = torch.tensor([0.3, 0.9]), torch.tensor([0.95, 0.43])
+    nz = rand((2, 6, 5, 5), 4)
+    want = ca[:, None, None, None] * x + cb[:, None, None, None] * nz
+    assert torch.equal(ops.q_sample(x.to(dev()), nz.to(dev()), ca.to(dev()), cb.to(dev())).cpu(), want)

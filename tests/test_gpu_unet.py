@@ -1,0 +1,234 @@
+"""-m gpu: the UNets and samplers end to end (HIP path through the reference-shaped classes) against
+the CPU oracle and the golden vectors captured from the reference.
+
+Tolerances (fp32, different accumulation order than oneDNN):
+  one UNet forward      rtol 1e-3 / atol 2e-4 on O(1) activations   (measured error is printed)
+  S-step sampler output atol 2e-3 on the [0,1] image, uint8 export within +-1 LSB
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import dev, nchw, close, report, rand, ReplayDeviceRng
+from detweights import det_state_dict, shapes_of
+from oracle import unet as OU, diffusion as OD
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    return {k: v for k, v in np.load(os.path.join(golden_dir, name + '.npz')).items()}
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def make_cfg(dim, seed=0, **kw):
+    from dmhomo_amd import cfg
+    m = cfg.Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1, **kw)
+    sd = det_state_dict(shapes_of(m), seed)
+    m.load_state_dict(sd)
+    return m.to(dev()), sd
+
+
+def make_ddp(dim, sc, seed=1):
+    from dmhomo_amd import ddpm
+    m = ddpm.Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=3, self_condition=sc)
+    sd = det_state_dict(shapes_of(m), seed)
+    m.load_state_dict(sd)
+    return m.to(dev()), sd
+
+
+def g(x):
+    return x.to(dev())
+
+
+# ------------------------------------------------------------------------------- UNet forward
+def test_unet_cfg_tiny_vs_golden(golden_dir):
+    """F1: reference outputs (dim=8, 32x32) incl. per-layer taps"""
+    gd = load(golden_dir, 'unet_cfg_tiny')
+    m, sd = make_cfg(8)
+    x, t, c, rf, mk = (T(gd[k]) for k in ('x', 't', 'classes', 'rgb_flow', 'mask'))
+    taps = {}
+    out = m._run(g(x), g(t), g(c), g(rf), g(mk), [None], taps=taps)
+    worst = 0.
+    for k, v in taps.items():
+        if 'tap.' + k in gd:
+            a, r = report('tap ' + k, nchw(v), T(gd['tap.' + k]))
+            worst = max(worst, r)
+    assert worst < 1e-3, worst
+    close('cfg tiny cond', out.cpu(), T(gd['out_cond']), rtol=1e-3, atol=2e-4)
+    out = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=1.)
+    close('cfg tiny null', out.cpu(), T(gd['out_null']), rtol=1e-3, atol=2e-4)
+    m.rng = ReplayDeviceRng([torch.where(T(gd['keep_half']), 0.25, 0.75)])     # uniform draw reproducing keep
+    out = m(g(x), g(t), g(c), g(rf), g(mk))
+    close('cfg tiny half', out.cpu(), T(gd['out_half']), rtol=1e-3, atol=2e-4)
+    m.rng = ReplayDeviceRng([torch.where(T(gd['keep_scale3']), 0.25, 0.75)])
+    out = m.forward_with_cond_scale(g(x), g(t), g(c), rgb_flow=g(rf), mask=g(mk), cond_scale=3.)
+    close('cfg tiny scale3', out.cpu(), T(gd['out_scale3']), rtol=1e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize('tag', ['nosc', 'sc'])
+def test_unet_ddp_tiny_vs_golden(golden_dir, tag):
+    gd = load(golden_dir, 'unet_ddp_tiny')
+    m, sd = make_ddp(8, tag == 'sc')
+    x, xs, t = T(gd['x']), T(gd['x_self_cond']), T(gd['t'])
+    if tag == 'sc':
+        close('ddp sc', m(g(x), g(t), g(xs)).cpu(), T(gd['sc.out']), rtol=1e-3, atol=2e-4)
+        close('ddp sc default', m(g(x), g(t)).cpu(), T(gd['sc.out_default']), rtol=1e-3, atol=2e-4)
+    else:
+        close('ddp nosc', m(g(x), g(t)).cpu(), T(gd['nosc.out']), rtol=1e-3, atol=2e-4)
+
+
+def _cond_inputs(B, S, seed):
+    x = rand((B, 6, S, S), seed)
+    rf = torch.rand((B, 3, S, S), generator=torch.Generator().manual_seed(seed + 1)) * 2 - 1
+    mk = (torch.rand((B, 1, S, S), generator=torch.Generator().manual_seed(seed + 2)) > 0.4).float()
+    return x, rf, mk
+
+
+def test_unet_cfg_fullsize_vs_oracle():
+    """BASELINE config geometry: dim=64, 128x128, B=2, per-layer taps against the oracle"""
+    m, sd = make_cfg(64)
+    x, rf, mk = _cond_inputs(2, 128, 100)
+    t = torch.tensor([967, 30])
+    c = torch.zeros(2, dtype=torch.long)
+    keep = torch.tensor([True, False])
+    rtaps, taps = {}, {}
+    with torch.no_grad():
+        ref = OU.cfg_unet_forward(sd, x, t, c, rf, mk, keep, taps=rtaps)
+    out = m._run(g(x), g(t), g(c), g(rf), g(mk), [g(keep.to(torch.uint8))], taps=taps)
+    worst = 0.
+    for k in rtaps:
+        a, r = report('full ' + k, nchw(taps[k]), rtaps[k])
+        worst = max(worst, r)
+    assert worst < 1e-3, worst
+    close('cfg full out', out.cpu(), ref, rtol=1e-3, atol=2e-4)
+
+
+def test_unet_rows_are_independent():
+    """size-independent property: each output row depends on its own sample only (bitwise) — what makes
+    sample-sharding across GPUs exact"""
+    m, sd = make_cfg(8)
+    x, rf, mk = _cond_inputs(5, 32, 200)
+    t = torch.full((5,), 499)
+    c = torch.zeros(5, dtype=torch.long)
+    full = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=0.)
+    part = m(g(x[3:]), g(t[3:]), g(c[3:]), g(rf[3:]), g(mk[3:]), cond_drop_prob=0.)
+    assert torch.equal(full[3:], part)
+    again = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=0.)
+    assert torch.equal(full, again)                       # deterministic: no atomics anywhere
+
+
+def test_unet_weight_update_is_picked_up():
+    m, sd = make_cfg(8)
+    x, rf, mk = _cond_inputs(1, 16, 300)
+    t, c = torch.tensor([5]), torch.zeros(1, dtype=torch.long)
+    a = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=0.).clone()
+    with torch.no_grad():
+        m.final_conv.bias.add_(1.0)
+    b = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=0.)
+    torch.testing.assert_close(b, a + 1.0, rtol=0, atol=1e-5)
+
+
+def test_cpu_tensor_fails_loudly():
+    m, sd = make_cfg(8)
+    x, rf, mk = _cond_inputs(1, 16, 300)
+    with pytest.raises(RuntimeError):
+        m(x, torch.tensor([5]), torch.zeros(1, dtype=torch.long), rf, mk)
+
+
+# ------------------------------------------------------------------------------- samplers
+@pytest.mark.parametrize('obj', ['pred_x0', 'pred_noise', 'pred_v'])
+def test_ddim_trace_vs_golden(golden_dir, obj):
+    """F5: the reference's own sample() run (S=4, 16x16) replaying its recorded RNG draws"""
+    from dmhomo_amd import cfg
+    gd = load(golden_dir, 'ddim_trace')
+    m, sd = make_cfg(8)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=4, objective=obj).to(dev())
+    d.rng = ReplayDeviceRng([gd[f'{obj}.draw{i}'] for i in range(8)])
+    trace = []
+    shape = (2, 6, 16, 16)
+    rgb = d.model  # noqa
+    from dmhomo_amd import ops
+    rgbn = ops.affine(g(T(gd['rgb_flow01'])), 2., -1.)
+    img, mk, fl = d.ddim_sample(g(T(gd['classes'])), rgbn, g(T(gd['flow'])), g(T(gd['mask'])), shape, trace=trace)
+    tol = 2e-3 if obj == 'pred_x0' else 2e-2          # pred_noise / pred_v divide by sqrt_recipm1 ~ 5e-5..1 (x20291 gain)
+    for i, st in enumerate(trace):
+        report(f'{obj} x_start{i}', st['x_start'].cpu(), T(gd[f'{obj}.x_start{i}']))
+    close(f'{obj} img', img.cpu(), T(gd[f'{obj}.img']), rtol=0, atol=tol)
+    assert d.rng.i == 8
+    # sample() = rgb_flow*2-1 + ddim_sample, same result
+    d.rng = ReplayDeviceRng([gd[f'{obj}.draw{i}'] for i in range(8)])
+    img2, mk2, fl2 = d.sample(g(T(gd['classes'])), g(T(gd['rgb_flow01'])), g(T(gd['flow'])), g(T(gd['mask'])))
+    assert torch.equal(img2, img) and torch.equal(mk2.cpu(), T(gd['mask'])) and torch.equal(fl2.cpu(), T(gd['flow']))
+    assert float(img.min()) >= 0 and float(img.max()) <= 1
+
+
+@pytest.mark.parametrize('tag', ['nosc', 'sc'])
+def test_ddpm_trace_vs_golden(golden_dir, tag):
+    """F6: DDP p_sample_loop (T=10), ddim_sample (S=4) and a single p_sample"""
+    from dmhomo_amd import ddpm
+    gd = load(golden_dir, 'ddpm_trace')
+    m, sd = make_ddp(8, tag == 'sc')
+    d = ddpm.GaussianDiffusion(m, image_size=16, timesteps=10, objective='pred_noise').to(dev())
+    d.rng = ReplayDeviceRng([gd[f'{tag}.ddpm.draw{i}'] for i in range(10)])
+    close(f'ddpm {tag}', d.sample(batch_size=2).cpu(), T(gd[f'{tag}.ddpm.img']), rtol=1e-3, atol=2e-3)
+    d2 = ddpm.GaussianDiffusion(m, image_size=16, timesteps=10, sampling_timesteps=4, objective='pred_x0').to(dev())
+    d2.rng = ReplayDeviceRng([gd[f'{tag}.ddim.draw{i}'] for i in range(4)])
+    close(f'ddp ddim {tag}', d2.sample(batch_size=2).cpu(), T(gd[f'{tag}.ddim.img']), rtol=1e-3, atol=0.5)
+    if tag == 'nosc':
+        d.rng = ReplayDeviceRng([gd['p_sample.noise']])
+        img, xs = d.p_sample(g(T(gd['p_sample.x'])), 5)
+        close('p_sample img', img.cpu(), T(gd['p_sample.img']), rtol=1e-3, atol=1e-3)
+        close('p_sample x_start', xs.cpu(), T(gd['p_sample.x_start']), rtol=1e-3, atol=1e-3)
+
+
+def test_sample_fullsize_vs_oracle_and_properties():
+    """config-1 geometry (dim=64, 128x128, bs=2, s_step=4): HIP sample() vs the oracle on replayed noise"""
+    from dmhomo_amd import cfg
+    from dmhomo_amd import ops
+    m, sd = make_cfg(64)
+    d = cfg.GaussianDiffusion(m, image_size=128, timesteps=1000, sampling_timesteps=4, objective='pred_x0').to(dev())
+    B = 2
+    _, rf, mk = _cond_inputs(B, 128, 400)
+    rf01 = (rf + 1) / 2
+    flow = rand((B, 2, 128, 128), 403)
+    c = torch.zeros(B, dtype=torch.long)
+    torch.manual_seed(99)
+    rec = OD.RecordRng()
+    buf = OD.schedule_buffers(1000, 'cosine')
+    with torch.no_grad():
+        ref, _, _ = OD.cfg_sample(sd, buf, c, rf01, flow, mk, image_size=128, channels=6, sampling_timesteps=4,
+                                  objective='pred_x0', rng=rec)
+    d.rng = ReplayDeviceRng(rec.draws)
+    img, mk2, fl2 = d.sample(g(c), g(rf01), g(flow), g(mk))
+    close('sample full', img.cpu(), ref, rtol=0, atol=2e-3)
+    u8 = ops.to_uint8(img).cpu().numpy().astype(np.int32)
+    ru8 = (ref.numpy() * 255).astype(np.uint8).astype(np.int32)
+    assert np.abs(u8 - ru8).max() <= 1
+    assert float(img.min()) >= 0 and float(img.max()) <= 1
+
+
+def test_state_dict_roundtrip_through_trainer(tmp_path):
+    """checkpoint dict layout of DDP:1786-1802 + Trainer.sample record format (G6)"""
+    from dmhomo_amd import cfg, ddpm
+    m, sd = make_cfg(8)
+    d = cfg.GaussianDiffusion(m, image_size=32, timesteps=1000, sampling_timesteps=2, objective='pred_x0').to(dev())
+    tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=3, results_folder=str(tmp_path), num_samples=4)
+    ret = tr.sample(0, 0, step=1)
+    assert ret['imgs'].dtype == np.uint8 and ret['imgs'].shape == (3, 6, 32, 32)
+    assert ret['homos'].dtype == np.float64 and ret['homos'].shape == (3, 3, 3)
+    tr.save(7)
+    ck = torch.load(str(tmp_path / 'model-7.pt'), map_location='cpu')
+    assert set(ck) == {'step', 'model', 'opt', 'ema', 'scaler', 'version'}
+    m2, _ = make_cfg(8, seed=5)
+    d2 = cfg.GaussianDiffusion(m2, image_size=32, timesteps=1000, sampling_timesteps=2, objective='pred_x0').to(dev())
+    tr2 = ddpm.Trainer(d2, 'DGM_Conditions', train_batch_size=3, results_folder=str(tmp_path))
+    tr2.load(7)
+    for (k, a), (_, b) in zip(d.state_dict().items(), d2.state_dict().items()):
+        assert torch.equal(a, b), k

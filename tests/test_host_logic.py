@@ -1,0 +1,91 @@
+"""CPU: host-side logic of the reference-shaped classes (no oracle, no GPU): state_dict layout,
+schedule buffers against the reference's golden values, DDIM time grid, constructor contracts."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope='module')
+def meta(golden_dir):
+    with open(os.path.join(golden_dir, 'meta.json')) as f:
+        return json.load(f)
+
+
+def shapes(m):
+    return {k: list(v.shape) for k, v in m.state_dict().items()}
+
+
+def test_state_dict_layout_matches_reference(meta):
+    from dmhomo_amd import cfg, ddpm
+    assert shapes(cfg.Unet(dim=8, channels=6, num_classes=1)) == meta['unet_cfg_tiny_keys']
+    m64 = cfg.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    assert shapes(m64) == meta['unet_cfg_dim64_keys']
+    assert sum(p.numel() for p in m64.parameters()) == 38417734
+    d = cfg.GaussianDiffusion(m64, image_size=128, timesteps=1000, sampling_timesteps=32, objective='pred_x0')
+    assert shapes(d) == meta['diffusion_cfg_dim64_keys']
+    assert shapes(ddpm.Unet(dim=8, channels=3)) == meta['unet_ddp_tiny_nosc_keys']
+    assert shapes(ddpm.Unet(dim=8, channels=3, self_condition=True)) == meta['unet_ddp_tiny_sc_keys']
+    assert shapes(ddpm.Unet(dim=64, channels=3)) == meta['unet_ddp_dim64_keys']
+
+
+def test_import_paths_of_the_reference_scripts():
+    from dmhomo_amd.denoising_diffusion_models.denoising_diffusion_pytorch import Trainer  # noqa: F401
+    from dmhomo_amd.denoising_diffusion_models.classifier_free_guidance import Unet, GaussianDiffusion  # noqa: F401
+
+
+def test_schedule_buffers_match_reference(golden_dir):
+    from dmhomo_amd import cfg, ddpm
+    from dmhomo_amd.schedule import ddim_pairs
+    g = np.load(os.path.join(golden_dir, 'schedule.npz'))
+    tiny = cfg.Unet(dim=8, channels=6, num_classes=1)
+    for sched, T in (('cosine', 1000), ('linear', 1000), ('cosine', 10)):
+        d = cfg.GaussianDiffusion(tiny, image_size=16, timesteps=T, beta_schedule=sched)
+        names = [k for k in d.state_dict() if not k.startswith('model.')]
+        assert len(names) == 13
+        for k in names:
+            v = d.state_dict()[k]
+            assert v.dtype == torch.float32 and torch.equal(v, torch.from_numpy(g[f'{sched}{T}.{k}'])), (sched, k)
+    d2 = ddpm.GaussianDiffusion(ddpm.Unet(dim=8, channels=3), image_size=16, timesteps=1000)
+    assert torch.equal(d2.alphas_cumprod, torch.from_numpy(g['cosine1000.alphas_cumprod']))
+    for S in (4, 32, 250):
+        pairs = ddim_pairs(1000, S)
+        assert [p[0] for p in pairs] + [pairs[-1][1]] == g[f'times{S}'].tolist()
+    assert [p[0] for p in ddim_pairs(1000, 1000)] == list(range(999, -1, -1))       # S == T grid
+
+
+def test_constructor_contracts():
+    from dmhomo_amd import cfg
+    m = cfg.Unet(dim=8, channels=6, num_classes=1)
+    assert (m.channels, m.out_dim, m.cond_drop_prob, m.random_or_learned_sinusoidal_cond) == (6, 6, 0.5, False)
+    with pytest.raises(ValueError):
+        cfg.GaussianDiffusion(m, image_size=16, beta_schedule='nope')
+    with pytest.raises(AssertionError):
+        cfg.GaussianDiffusion(m, image_size=16, objective='bad')
+    with pytest.raises(AssertionError):
+        cfg.GaussianDiffusion(cfg.Unet(dim=8, channels=6, num_classes=1, out_dim=3), image_size=16)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=32)
+    assert d.is_ddim_sampling and d.num_timesteps == 1000 and d.sampling_timesteps == 32
+    assert not cfg.GaussianDiffusion(m, image_size=16).is_ddim_sampling
+    with pytest.raises(TypeError):       # the reference's ancestral path is uncallable
+        cfg.GaussianDiffusion(m, image_size=16).sample(torch.zeros(1, dtype=torch.long), None, None, None)
+
+
+def test_no_cpu_path():
+    from dmhomo_amd import cfg
+    m = cfg.Unet(dim=8, channels=6, num_classes=1)
+    x = torch.zeros(1, 6, 16, 16)
+    with pytest.raises(RuntimeError, match='GPU'):
+        m(x, torch.zeros(1, dtype=torch.long), torch.zeros(1, dtype=torch.long), torch.zeros(1, 3, 16, 16),
+          torch.zeros(1, 1, 16, 16))
+
+
+def test_product_does_not_import_the_oracle():
+    import subprocess
+    import sys
+    code = 'import sys, dmhomo_amd, dmhomo_amd.distributed; print(any(m == "oracle" or m.startswith("oracle.") for m in sys.modules))'
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == 'False', out.stdout + out.stderr
