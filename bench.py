@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sampled images/sec of the DGM denoising hot path (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], README inference config at 128x128): CFG Unet dim=64,
+dim_mults (1,2,4,8), channels=6, GaussianDiffusion(image_size=128, timesteps=1000,
+sampling_timesteps=32, objective='pred_x0'), cond_scale=3 (2 UNet forwards per denoise step,
+run as one 2B batch), bs=25 per GPU.  One "step" = one pass of the hot path over one batch:
+sample() (32 denoise steps) + the uint8 / homography record of Trainer.sample + (N>1) the
+gather to rank 0.  Inputs (conditions, weights) are resident in HBM before the timed region;
+weights are seeded random init (the trained DGM.pt is not available offline; speed is weight
+independent), noise comes from the device Philox generator.  Samples shard across ranks with no
+data-path collective -> "scaling": "weak" (25 samples per GPU).
+
+Prints ONE JSON line on rank 0, including
+  roofline     the dominant kernel (3x3 implicit-GEMM conv on fp32 MFMA): algorithmic FLOPs of
+               its launches in the timed region / their HIP-event durations, vs the 157.3 TFLOP/s
+               dense fp32 matrix peak of MI355X (MI355X_MICROARCH.md)
+  cpu_baseline the oracle (a port of the reference's CPU path, bit-equal to it on the build host)
+               timed on this box's host cores on a bounded sample (bs=2, s_step=4, same network).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def cpu_baseline(dim, image_size, seconds=12.0):
+    """oracle (kind 'port') on the host cores: bs=2, s_step=4 passes of the same network, reported as
+    images/s at s_step=32 (cost per denoise step is constant, so x 4/32)."""
+    from oracle import diffusion as OD
+    from detweights import det_state_dict, shapes_of
+    from dmhomo_amd import cfg
+    m = cfg.Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    sd = det_state_dict(shapes_of(m))
+    buf = OD.schedule_buffers(1000, 'cosine')
+    B, S = 2, 4
+    g = torch.Generator().manual_seed(1)
+    rgb = torch.rand((B, 3, image_size, image_size), generator=g)
+    mask = (torch.rand((B, 1, image_size, image_size), generator=g) > 0.5).float()
+    flow = torch.zeros((B, 2, image_size, image_size))
+    classes = torch.zeros(B, dtype=torch.long)
+    # 16 threads is the fastest setting for this bs=2 workload on the 128-core GPU-box host (8: 0.24 s,
+    # 16: 0.13 s, 32: 0.26 s, 128: 1.24 s per UNet forward; tools/cpu_threads.py) — oneDNN over-threads beyond that
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+
+    def one():
+        with torch.no_grad():
+            OD.cfg_sample(sd, buf, classes, rgb, flow, mask, image_size=image_size, channels=6,
+                          sampling_timesteps=S, objective='pred_x0')
+    one()                                               # warm-up (oneDNN primitive caches)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 6:
+            break
+    per_pass = el / n
+    return {'value': B * (S / 32.0) / per_pass, 'unit': 'images/s (s_step=32 equivalent)', 'cores': cores,
+            'kind': 'port',
+            'sample': f'oracle cfg_sample bs={B} s_step={S} {image_size}x{image_size} dim={dim}, {n} passes, '
+                      f'{per_pass:.2f} s/pass = {per_pass / S * 1000:.0f} ms per denoise step (bs={B}); '
+                      f'images/s scaled by 4/32 to s_step=32'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--bs', type=int, default=25, help='samples per GPU')
+    ap.add_argument('--s_step', type=int, default=32)
+    ap.add_argument('--image_size', type=int, default=128)
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-conv-events', action='store_true', help='skip the per-launch HIP events')
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from dmhomo_amd import cfg, ddpm, ops
+    from dmhomo_amd import distributed as D
+
+    rank, world, device = D.init_from_env()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    assert device.type == 'cuda', 'bench.py needs MI355X GPUs (no CPU path)'
+
+    # ---- model: seeded init on every rank, then rank 0's weights win (one scatter+all-gather payload)
+    torch.manual_seed(0)
+    model = cfg.Unet(dim=args.dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    diffusion = cfg.GaussianDiffusion(model, image_size=args.image_size, timesteps=1000,
+                                      sampling_timesteps=args.s_step, loss_type='l1', objective='pred_x0').to(device)
+    D.broadcast_module_(diffusion, src=0)
+    torch.manual_seed(99 + rank)                         # device Philox stream for the noise
+
+    # ---- synthetic conditions of this rank's shard, resident in HBM
+    lo, hi = D.shard_bounds(args.bs * world, rank, world)
+    conds = ddpm.SyntheticConditions(args.image_size, hi - lo, seed=1000 + lo, device=device)
+    data, classes = next(conds)
+    rgb_flow, flow, mask = data[:, -5:-2].contiguous(), data[:, -2:].contiguous(), data[:, -6:-5].contiguous()
+
+    def step():
+        img, _, fl = diffusion.sample(classes, rgb_flow, flow, mask)          # cond_scale=3 (CFG:714)
+        imgs_u8 = ops.to_uint8(img)
+        homos = ops.dlt_homography(fl)
+        return D.gather_records(imgs_u8, homos, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.CONV_LOG = None if args.no_conv_events else []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    log, ops.CONV_LOG = ops.CONV_LOG, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = args.bs * world * args.steps
+        res = {
+            'metric': 'sampled images/sec (128x128, s_step=32)', 'value': images / elapsed, 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'ms_per_denoise_step': elapsed / args.steps / args.s_step * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'DGM CFG-Unet dim={args.dim} {args.image_size}x{args.image_size} '
+                                   f'bs={args.bs}/GPU s_step={args.s_step} cond_scale=3 (BASELINE configs[1])',
+                       'global_batch': args.bs * world, 'sharding': f'samples x{world}, no data-path collective',
+                       'weights': 'seeded random init', 'noise': 'device Philox'},
+        }
+        if log:
+            fl3 = ms3 = n3 = 0.0
+            flc = msc = nc = 0.0
+            for e0, e1, k, stride, B, ho, wo, cin, cout in log:
+                if k != 3:
+                    continue
+                ms = e0.elapsed_time(e1)
+                fl = 2.0 * 9 * cin * cout * ho * wo * B
+                fl3, ms3, n3 = fl3 + fl, ms3 + ms, n3 + 1
+                if (cin, cout, ho) == (64, 64, args.image_size):
+                    flc, msc, nc = flc + fl, msc + ms, nc + 1
+            ach = fl3 / (ms3 * 1e-3) / 1e12
+            res['roofline'] = {
+                'kernel': 'conv_igemm_kernel<3,3,1,*> (3x3 conv, implicit GEMM on v_mfma_f32_32x32x2_f32)',
+                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                'launches': int(n3), 'avg_launch_us': ms3 / n3 * 1e3,
+                'time_share_of_step': ms3 * 1e-3 / elapsed,
+                'canonical_64to64_128sq': {'launches': int(nc), 'avg_launch_us': msc / max(nc, 1) * 1e3,
+                                           'TFLOP/s': (flc / (msc * 1e-3) / 1e12) if msc else None,
+                                           'GB/s_algorithmic': (nc * (4.0 * 2 * args.bs * args.image_size ** 2 * 128
+                                                                      + 4 * (9 * 64 * 64 + 3 * 64))
+                                                                / (msc * 1e-3) / 1e9) if msc else None},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.dim, args.image_size)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

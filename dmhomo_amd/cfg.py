@@ -135,7 +135,10 @@ class ScheduleHost:
         alpha = host['alphas_cumprod'][time]
         alpha_next = host['alphas_cumprod'][time_next]
         sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
-        c = (1 - alpha_next - sigma ** 2).sqrt()
+        # For a first jump from t=T-1 (alpha ~ 2e-9) to alpha_next >~ 1e-2 (s_step <= 8) the radicand is pure fp32
+        # cancellation noise of +-6e-8 and the reference yields c = NaN on hosts whose sqrt rounds the other way
+        # (seen: 999 -> 499).  Clamping at 0 changes nothing where the reference is finite.
+        c = (1 - alpha_next - sigma ** 2).clamp(min=0).sqrt()
         return float(alpha_next.sqrt()), float(c), float(sigma)
 
 

@@ -51,6 +51,11 @@ def conv_out_hw(pc, h, w):
     return h, w
 
 
+# launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline leg):
+# when a list, every dmh_conv2d launch appends (start_event, end_event, k, stride, B, Hout, Wout, Cin, Cout)
+CONV_LOG = None
+
+
 def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False):
     """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats)."""
     B, H, W, c0 = src0.shape
@@ -67,7 +72,14 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
         assert res.shape == out.shape, (res.shape, out.shape)
     d = _lib.DmhConv(ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
                      ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2)
-    call('dmh_conv2d', C.byref(d))
+    if CONV_LOG is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call('dmh_conv2d', C.byref(d))
+        e1.record()
+        CONV_LOG.append((e0, e1, pc.k, pc.stride, B, ho, wo, pc.c0 + pc.c1, pc.cout))
+    else:
+        call('dmh_conv2d', C.byref(d))
     return (out, stats) if want_stats else out
 
 

@@ -166,14 +166,14 @@ def test_linear_attention_core(ops, H, W):
 
 
 def test_linear_attention_uniform_k_gives_mean_v(ops):
-    """known answer: constant k -> softmax_n uniform -> ctx[d][e] = mean_n v[e] for every d"""
+    """known answer: constant k -> softmax_n uniform -> ctx[d][e] = mean_n(v[e]) / n for every d (v is scaled by 1/n)"""
     H = W = 12
     qkv = rand((1, 384, H, W), 19)
     qkv[:, 128:256] = 0.37
     out = nchw(ops.linear_attention_core(nhwc(qkv), 32 ** -0.5))
     q, k, v = _split_heads(qkv)
     qs = q.softmax(dim=-2) * 32 ** -0.5                       # sums to scale over d
-    want = v.mean(-1)[..., None] * qs.sum(2, keepdim=True)     # (b,h,e,n)
+    want = (v.mean(-1) / (H * W))[..., None] * qs.sum(2, keepdim=True)     # (b,h,e,n)
     close('linattn uniform-k', out, want.reshape(1, 128, H, W), rtol=1e-4, atol=1e-6)
 
 

@@ -153,7 +153,6 @@ def test_ddim_trace_vs_golden(golden_dir, obj):
     d.rng = ReplayDeviceRng([gd[f'{obj}.draw{i}'] for i in range(8)])
     trace = []
     shape = (2, 6, 16, 16)
-    rgb = d.model  # noqa
     from dmhomo_amd import ops
     rgbn = ops.affine(g(T(gd['rgb_flow01'])), 2., -1.)
     img, mk, fl = d.ddim_sample(g(T(gd['classes'])), rgbn, g(T(gd['flow'])), g(T(gd['mask'])), shape, trace=trace)
@@ -189,11 +188,13 @@ def test_ddpm_trace_vs_golden(golden_dir, tag):
 
 
 def test_sample_fullsize_vs_oracle_and_properties():
-    """config-1 geometry (dim=64, 128x128, bs=2, s_step=4): HIP sample() vs the oracle on replayed noise"""
+    """config-1 geometry (dim=64, 128x128, bs=2, s_step=4): HIP sample() vs the oracle on replayed noise.
+    timesteps=100 keeps the first DDIM jump (99 -> 74) out of the regime where the reference's
+    c = sqrt(1 - a' - sigma^2) is pure fp32 cancellation noise (999 -> 749 at T=1000: 0 or NaN by host)."""
     from dmhomo_amd import cfg
     from dmhomo_amd import ops
     m, sd = make_cfg(64)
-    d = cfg.GaussianDiffusion(m, image_size=128, timesteps=1000, sampling_timesteps=4, objective='pred_x0').to(dev())
+    d = cfg.GaussianDiffusion(m, image_size=128, timesteps=100, sampling_timesteps=4, objective='pred_x0').to(dev())
     B = 2
     _, rf, mk = _cond_inputs(B, 128, 400)
     rf01 = (rf + 1) / 2
@@ -201,7 +202,7 @@ def test_sample_fullsize_vs_oracle_and_properties():
     c = torch.zeros(B, dtype=torch.long)
     torch.manual_seed(99)
     rec = OD.RecordRng()
-    buf = OD.schedule_buffers(1000, 'cosine')
+    buf = OD.schedule_buffers(100, 'cosine')
     with torch.no_grad():
         ref, _, _ = OD.cfg_sample(sd, buf, c, rf01, flow, mk, image_size=128, channels=6, sampling_timesteps=4,
                                   objective='pred_x0', rng=rec)
