@@ -87,6 +87,7 @@ def main():
     ap.add_argument('--image_size', type=int, default=128)
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cfg-mode', default='batched', choices=['batched', 'streams'])
     ap.add_argument('--no-conv-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
 
@@ -101,6 +102,7 @@ def main():
     # ---- model: seeded init on every rank, then rank 0's weights win (one scatter+all-gather payload)
     torch.manual_seed(0)
     model = cfg.Unet(dim=args.dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    model.cfg_mode = args.cfg_mode
     diffusion = cfg.GaussianDiffusion(model, image_size=args.image_size, timesteps=1000,
                                       sampling_timesteps=args.s_step, loss_type='l1', objective='pred_x0').to(device)
     D.broadcast_module_(diffusion, src=0)

@@ -101,11 +101,29 @@ class Unet(nn.Module):
         keep = self._keep_mask(x.shape[0], cond_drop_prob, x.device)
         return self._run(x, time, classes, rgb_flow, mask, [keep])
 
+    # 'batched': cond + null rows as ONE 2B launch sequence.  'streams': the two passes as two B-row
+    # sequences on two HIP streams, so one pass's HBM-bound kernels and kernel tails overlap the other's
+    # matrix-bound kernels.  Results are identical (rows are independent, tests pin that bitwise).
+    cfg_mode = 'batched'
+
     def _cond_null(self, x, time, classes, rgb_flow, mask):
-        """the two passes of CFG:404,409 as ONE batch of 2B rows: (cond logits, null logits)."""
+        """the two passes of CFG:404,409: (cond logits, null logits)."""
         B = x.shape[0]
         keep = self._keep_mask(B, self.cond_drop_prob, x.device)
         null = torch.zeros((B,), device=x.device, dtype=torch.uint8)
+        if self.cfg_mode == 'streams':
+            if not hasattr(self, '_side'):
+                self._side = (torch.cuda.Stream(device=x.device), torch.cuda.Stream(device=x.device))
+            cur = torch.cuda.current_stream()
+            outs = []
+            for st, k in zip(self._side, (keep, null)):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    outs.append(self._run(x, time, classes, rgb_flow, mask, [k]))
+            for st, o in zip(self._side, outs):
+                cur.wait_stream(st)
+                o.record_stream(cur)
+            return outs[0], outs[1]
         both = self._run(x, time, classes, rgb_flow, mask, [keep, null])
         return both[:B], both[B:]
 

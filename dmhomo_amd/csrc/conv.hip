@@ -9,11 +9,21 @@
 // pending — and reused by all KH*KW taps; the weight tile of each tap is double buffered.
 // The contraction runs on v_mfma_f32_32x32x2_f32 (exact fp32: a k-ordered fmaf chain), four
 // waves side by side along M, each owning MB x 2 accumulator blocks of 32x32.
-// Epilogue: + bias, + residual (optionally through SiLU(a*res+b)), NHWC store, and the
-// per-tile (sum, sum^2) per output channel that GroupNorm needs (fixed order, no atomics).
+// Epilogue: accumulators -> LDS transpose -> + bias, + residual (optionally through
+// SiLU(a*res+b)), 16 B-per-lane NHWC stores, and the per-tile (sum, sum^2) per output channel
+// that GroupNorm needs (fixed order, no atomics).
+//
+// Two main loops share that epilogue:
+//   conv_igemm_kernel   weight tile of each tap staged in LDS (double buffered, one barrier per tap);
+//                       used for 1x1, 7x7 and the strided variants
+//   conv_stream_kernel  3x3 hot path: B fragments stream straight from L2 into registers in
+//                       fragment-major order (one coalesced 1 KB load per wave-instruction, prefetched a
+//                       tap ahead), the input tile is double buffered => ONE barrier per channel chunk
 //
 // Replaces: F.conv2d of WeightStandardizedConv2d CFG:128, Downsample CFG:110-111 /
 // DDP:110-113, Upsample CFG:106-107, to_qkv / to_out / res_conv 1x1 convs, init_conv CFG:333.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -46,11 +56,120 @@ struct ConvCfg {
   static constexpr int PAD = (S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0);
   static constexpr int IN_FLOATS = IN_PIX * KCP;
   static constexpr int W_FLOATS = 64 * KCP;
-  static constexpr int LDS_BYTES = (IN_FLOATS + 2 * W_FLOATS) * 4;
+  static constexpr int EPI_BYTES = 4 * 32 * 68 * 4;  // epilogue transpose scratch: 4 waves x 32 rows x (64+4)
+  static constexpr int MAIN_BYTES = (IN_FLOATS + 2 * W_FLOATS) * 4;
+  static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  static constexpr int STREAM_MAIN = 2 * IN_FLOATS * 4;
+  static constexpr int STREAM_LDS = STREAM_MAIN > EPI_BYTES ? STREAM_MAIN : EPI_BYTES;
 };
 
-template <int KH, int KW, int S, int UPS, int KC, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
+// ---- shared epilogue.  C/D layout of a 32x32 block: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Each wave transposes its rows through a private LDS slab so that 16 lanes cover one pixel's 64 channels
+// with float4 accesses (bias / residual / stores all 16 B per lane).
+template <int MB, int TH, int TW>
+__device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[MB][2], const ConvArgs& p, float* lds, int b, int n0,
+                                              int oy0, int ox0, int tile_in_sample) {
+  constexpr int EP = 68;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  const int c4 = lane & 15, rsub = lane >> 4;
+  const int chn = n0 + c4 * 4;
+  const bool cok = chn < p.Cout;  // Cout % 4 == 0
+  float* wl = lds + wave * (32 * EP);
+  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), ra = bias, rb = bias;
+  if (cok && p.bias) bias = ld4(p.bias + chn);
+  if (cok && p.res_coef) {
+    ra = ld4(p.res_coef + (size_t)(b * 2 + 0) * p.Cout + chn);
+    rb = ld4(p.res_coef + (size_t)(b * 2 + 1) * p.Cout + chn);
+  }
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    __syncthreads();  // main loop (or the previous half) is done with this LDS
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * half) * EP + nb * 32 + l31] = acc[mb][nb][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = i * 4 + rsub;
+      const int row = wave * (MB * 32) + mb * 32 + rr;
+      const int oy = oy0 + row / TW, ox = ox0 + row % TW;
+      if (cok && oy < p.Hout && ox < p.Wout) {
+        float4 val = ld4(wl + rr * EP + c4 * 4);
+        const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;
+        val.x += bias.x;
+        val.y += bias.y;
+        val.z += bias.z;
+        val.w += bias.w;
+        if (p.res) {
+          const float4 rv = ld4(p.res + o);
+          if (p.res_coef) {
+            val.x += silu_f(fmaf(ra.x, rv.x, rb.x));
+            val.y += silu_f(fmaf(ra.y, rv.y, rb.y));
+            val.z += silu_f(fmaf(ra.z, rv.z, rb.z));
+            val.w += silu_f(fmaf(ra.w, rv.w, rb.w));
+          } else {
+            val.x += rv.x;
+            val.y += rv.y;
+            val.z += rv.z;
+            val.w += rv.w;
+          }
+        }
+        st4(p.out + o, val);
+        s1.x += val.x;
+        s1.y += val.y;
+        s1.z += val.z;
+        s1.w += val.w;
+        s2.x = fmaf(val.x, val.x, s2.x);
+        s2.y = fmaf(val.y, val.y, s2.y);
+        s2.z = fmaf(val.z, val.z, s2.z);
+        s2.w = fmaf(val.w, val.w, s2.w);
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      s1.x += __shfl_xor(s1.x, off);
+      s1.y += __shfl_xor(s1.y, off);
+      s1.z += __shfl_xor(s1.z, off);
+      s1.w += __shfl_xor(s1.w, off);
+      s2.x += __shfl_xor(s2.x, off);
+      s2.y += __shfl_xor(s2.y, off);
+      s2.z += __shfl_xor(s2.z, off);
+      s2.w += __shfl_xor(s2.w, off);
+    }
+    __syncthreads();  // every wave is done with its transpose slab: reuse LDS as the cross-wave scratch
+    float* red = lds;
+    if (lane < 16) {
+      float* q = red + (wave * 64 + c4 * 4) * 2;
+      q[0] = s1.x;
+      q[1] = s2.x;
+      q[2] = s1.y;
+      q[3] = s2.y;
+      q[4] = s1.z;
+      q[5] = s2.z;
+      q[6] = s1.w;
+      q[7] = s2.w;
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.Cout) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a0 += red[(w * 64 + tid) * 2 + 0];
+        a1 += red[(w * 64 + tid) * 2 + 1];
+      }
+      float* st = p.stats + ((size_t)(b * p.tilesX * p.tilesY + tile_in_sample) * p.Cout + n0 + tid) * 2;
+      st[0] = a0;
+      st[1] = a1;
+    }
+  }
+}
+
+template <int KH, int KW, int S, int UPS, int KC, int TH, int TW, int WPE>
+__global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
   using Cfg = ConvCfg<KH, KW, S, UPS, KC, TH, TW>;
   constexpr int MB = Cfg::MB, IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, KCP = Cfg::KCP, C4 = Cfg::C4;
   constexpr int NLOAD = Cfg::NLOAD, WL = Cfg::WL, NTAPS = KH * KW;
@@ -108,16 +227,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
   const int c4 = tid % C4;  // 256 % C4 == 0: a thread keeps its channel quad across its pixels
   int wbuf = 0;
 
-  for (int ch = 0; ch < nchunks; ++ch) {
+  // input (halo) tile of one channel chunk: global -> registers (issued one phase ahead of its use)
+  float4 v[NLOAD];
+  float4 ca, cb;
+  unsigned inside;  // bit i: slot i holds image data (not zero padding)
+  auto issue_chunk_loads = [&](int ch) {
     const bool s1 = ch >= p.nch0;
     const float* src = s1 ? p.src1 : p.src0;
     const int Csrc = s1 ? p.C1 : p.C0;
     const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
     const bool cvalid = c < Csrc;
-
-    // ---- stage the input (halo) tile of this channel chunk: global -> regs -> (prologue) -> LDS
-    float4 v[NLOAD];
-    unsigned inside = 0;  // bit i: slot i holds image data (not zero padding)
+    inside = 0;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int f = tid + i * 256;
@@ -133,13 +253,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
         }
       }
     }
-    float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool pro = (p.in_coef != nullptr) && !s1;
-    if (pro && cvalid) {
+    ca = make_float4(1.f, 1.f, 1.f, 1.f);
+    cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.in_coef != nullptr && !s1 && cvalid) {
       ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + c);
       cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + c);
     }
+  };
+  issue_chunk_loads(0);
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const bool pro = (p.in_coef != nullptr) && ch < p.nch0;
     __syncthreads();  // every wave is done reading in_tile of the previous chunk
+    // ---- registers -> (prologue SiLU(a*x+b)) -> LDS
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int f = tid + i * 256;
@@ -147,10 +273,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
       if (pix < IN_PIX) {
         float4 x = v[i];
         if (pro && ((inside >> i) & 1u)) {  // padding stays exactly zero: it pads the ACTIVATED tensor
-          x.x = silu_f(fmaf(ca.x, x.x, cb.x));
-          x.y = silu_f(fmaf(ca.y, x.y, cb.y));
-          x.z = silu_f(fmaf(ca.z, x.z, cb.z));
-          x.w = silu_f(fmaf(ca.w, x.w, cb.w));
+          x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
+          x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
+          x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
+          x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
         }
         st4(in_tile + pix * KCP + c4 * 4, x);
       }
@@ -176,7 +302,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
 #pragma unroll
           for (int i = 0; i < WL; ++i) wreg[i] = ld4(wsrc + (size_t)(tid + i * 256) * 4);
         }
+        // the next chunk's input tile travels during the last tap phase of this one
+        if (tap == NTAPS - 1 && ch + 1 < nchunks) issue_chunk_loads(ch + 1);
       }
+      // keep the prefetch loads ABOVE the matrix phase (hipcc otherwise sinks them next to their
+      // consumer and the global latency lands on the critical path of every phase)
+      __builtin_amdgcn_sched_barrier(0);
       const int kh = tap / KW, kw = tap % KW;
       const float* at = in_tile + (kh * IN_W + kw) * KCP;
       const float* bt = wt + brow;
@@ -197,82 +328,201 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, bq[nb].w, acc[mb][nb], 0, 0, 0);
           }
       }
+      __builtin_amdgcn_sched_barrier(0);
       wbuf ^= 1;
     }
   }
 
-  // ---- epilogue.  C/D layout of the 32x32 block: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  conv_epilogue<MB, TH, TW>(acc, p, lds, b, n0, oy0, ox0, tile_in_sample);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 hot path.  Same tiling, but the weight (B) fragments never touch LDS: the packed image is
+// fragment-major ([chunk][tap][k8][nb][lane][4]) so each wave-instruction is one coalesced 1 KB load that
+// lands directly in the MFMA operand registers, issued a whole tap (>= 2048 matrix cycles) ahead; the four
+// waves of a workgroup hit the same lines (L1/L2).  The input tile is double buffered, so the only
+// workgroup barrier left is the one that publishes the next channel chunk.
+template <int UPS, int KC, int TH, int TW, int WPE>
+__global__ __launch_bounds__(256, WPE) void conv_stream_kernel(ConvArgs p) {
+  using Cfg = ConvCfg<3, 3, 1, UPS, KC, TH, TW>;
+  constexpr int MB = Cfg::MB, IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, KCP = Cfg::KCP, C4 = Cfg::C4;
+  constexpr int NLOAD = Cfg::NLOAD, NTAPS = 9, K8 = KC / 8, NB4 = K8 * 2;  // NB4 float4 of B per lane per tap
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tilesX;
+  t /= p.tilesX;
+  const int ty = t % p.tilesY;
+  const int b = t / p.tilesY;
+  const int nt = blockIdx.y;
+  const int n0 = nt * 64;
+  const int tile_in_sample = ty * p.tilesX + tx;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const int Hlim = UPS ? p.Hin * 2 : p.Hin;
+  const int Wlim = UPS ? p.Win * 2 : p.Win;
+
+  int arow[MB];
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int chn = n0 + nb * 32 + l31;
-    const bool cok = chn < p.Cout;
-    const float bias = (cok && p.bias) ? p.bias[chn] : 0.f;
-    float ra = 1.f, rb = 0.f;
-    if (cok && p.res_coef) {
-      ra = p.res_coef[(size_t)(b * 2 + 0) * p.Cout + chn];
-      rb = p.res_coef[(size_t)(b * 2 + 1) * p.Cout + chn];
-    }
+  for (int mb = 0; mb < MB; ++mb) {
+    const int r = wave * (MB * 32) + mb * 32 + l31;
+    arow[mb] = ((r / TW) * IN_W + (r % TW)) * KCP + half * 4;
+  }
+
+  floatx16 acc[MB][2];
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wave * (MB * 32) + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int oy = oy0 + row / TW, ox = ox0 + row % TW;
-        if (cok && oy < p.Hout && ox < p.Wout) {
-          const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;
-          float val = acc[mb][nb][r] + bias;
-          if (p.res) {
-            const float rv = p.res[o];
-            val += p.res_coef ? silu_f(fmaf(ra, rv, rb)) : rv;
-          }
-          p.out[o] = val;
-          s1[nb] += val;
-          s2[nb] = fmaf(val, val, s2[nb]);
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  const int nchunks = p.nch0 + p.nch1;
+  const float* wbase = p.wpack + (size_t)nt * nchunks * NTAPS * 64 * KC + lane * 4;
+  const int c4 = tid % C4;
+
+  float4 v[NLOAD];
+  float4 ca, cb;
+  unsigned inside;
+  auto issue_chunk_loads = [&](int ch) {
+    const bool s1 = ch >= p.nch0;
+    const float* src = s1 ? p.src1 : p.src0;
+    const int Csrc = s1 ? p.C1 : p.C0;
+    const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
+    const bool cvalid = c < Csrc;
+    inside = 0;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int f = tid + i * 256;
+      const int pix = f / C4;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pix < IN_PIX && cvalid) {
+        const int hy = pix / IN_W, hx = pix % IN_W;
+        const int yy = iy0 + hy, xx = ix0 + hx;
+        if (yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim) {
+          const int sy = UPS ? (yy >> 1) : yy, sx = UPS ? (xx >> 1) : xx;
+          v[i] = ld4(src + ((size_t)(b * p.Hin + sy) * p.Win + sx) * Csrc + c);
+          inside |= 1u << i;
         }
       }
     }
-  }
-  if (p.stats) {
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-      s1[nb] += __shfl_xor(s1[nb], 32);
-      s2[nb] += __shfl_xor(s2[nb], 32);
+    ca = make_float4(1.f, 1.f, 1.f, 1.f);
+    cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.in_coef != nullptr && !s1 && cvalid) {
+      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + c);
+      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + c);
     }
-    __syncthreads();  // all waves are done with in_tile: reuse it as the cross-wave scratch
-    float* red = lds;
-    if (half == 0) {
+  };
+  auto write_chunk = [&](int ch) {  // registers -> (prologue SiLU(a*x+b)) -> LDS buffer ch & 1
+    const bool pro = (p.in_coef != nullptr) && ch < p.nch0;
+    float* dst = lds + (ch & 1) * Cfg::IN_FLOATS;
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
-        red[(wave * 64 + nb * 32 + l31) * 2 + 0] = s1[nb];
-        red[(wave * 64 + nb * 32 + l31) * 2 + 1] = s2[nb];
+    for (int i = 0; i < NLOAD; ++i) {
+      const int f = tid + i * 256;
+      const int pix = f / C4;
+      if (pix < IN_PIX) {
+        float4 x = v[i];
+        if (pro && ((inside >> i) & 1u)) {  // padding stays exactly zero: it pads the ACTIVATED tensor
+          x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
+          x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
+          x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
+          x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
+        }
+        st4(dst + pix * KCP + c4 * 4, x);
       }
     }
-    __syncthreads();
-    if (tid < 64 && n0 + tid < p.Cout) {
-      float a0 = 0.f, a1 = 0.f;
+  };
+
+  float4 bn[NB4];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        a0 += red[(w * 64 + tid) * 2 + 0];
-        a1 += red[(w * 64 + tid) * 2 + 1];
+  for (int i = 0; i < NB4; ++i) bn[i] = ld4(wbase + (size_t)i * 256);
+  issue_chunk_loads(0);
+  write_chunk(0);
+  __syncthreads();
+
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float* in_tile = lds + (ch & 1) * Cfg::IN_FLOATS;
+#pragma unroll
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      float4 bc[NB4];
+#pragma unroll
+      for (int i = 0; i < NB4; ++i) bc[i] = bn[i];
+      {
+        int nch = ch, ntap = tap + 1;
+        if (ntap == NTAPS) {
+          ntap = 0;
+          nch = ch + 1;
+        }
+        if (nch < nchunks) {
+          const float* wsrc = wbase + ((size_t)nch * NTAPS + ntap) * 64 * KC;
+#pragma unroll
+          for (int i = 0; i < NB4; ++i) bn[i] = ld4(wsrc + (size_t)i * 256);
+        }
+        if (tap == NTAPS - 1 && ch + 1 < nchunks) issue_chunk_loads(ch + 1);
       }
-      float* st = p.stats + ((size_t)(b * p.tilesX * p.tilesY + tile_in_sample) * p.Cout + n0 + tid) * 2;
-      st[0] = a0;
-      st[1] = a1;
+      __builtin_amdgcn_sched_barrier(0);  // prefetches stay above the matrix phase
+      const float* at = in_tile + ((tap / 3) * IN_W + (tap % 3)) * KCP;
+#pragma unroll
+      for (int k8 = 0; k8 < K8; ++k8) {
+        float4 a[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) a[mb] = ld4(at + arow[mb] + k8 * 8);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            const float4 bq = bc[k8 * 2 + nb];
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, bq.x, acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].y, bq.y, acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].z, bq.z, acc[mb][nb], 0, 0, 0);
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, bq.w, acc[mb][nb], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ch + 1 < nchunks) {
+      write_chunk(ch + 1);  // other buffer: nobody reads it until the barrier below
+      __syncthreads();
     }
   }
+  conv_epilogue<MB, TH, TW>(acc, p, lds, b, n0, oy0, ox0, tile_in_sample);
 }
 
 // ------------------------------------------------------------------------------ weight packing
+// layout 0: [ntile][chunk][tap][col 64][k KC]           (weight tile copied into LDS)
+// layout 1: [ntile][chunk][tap][k8][nb][lane 64][4]      (fragment-major: lane = half*32 + col%32 holds
+//           k = k8*8 + half*4 + e of column nb*32 + col%32 — exactly one MFMA B operand quad)
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int C0,
-                                        int C1, int KH, int KW, int KC, int nch0, int nch1, int64_t total) {
+                                        int C1, int KH, int KW, int KC, int nch0, int nch1, int layout,
+                                        int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int64_t r = idx;
-  const int k = r % KC;
-  r /= KC;
-  const int j = r % 64;
-  r /= 64;
+  int k, j;
+  if (layout == 0) {
+    k = r % KC;
+    r /= KC;
+    j = r % 64;
+    r /= 64;
+  } else {
+    const int e = r % 4;
+    r /= 4;
+    const int lane = r % 64;
+    r /= 64;
+    const int nb = r % 2;
+    r /= 2;
+    const int k8 = r % (KC / 8);
+    r /= (KC / 8);
+    k = k8 * 8 + (lane >> 5) * 4 + e;
+    j = nb * 32 + (lane & 31);
+  }
   const int tap = r % (KH * KW);
   r /= (KH * KW);
   const int ch = r % (nch0 + nch1);
@@ -319,9 +569,29 @@ __global__ __launch_bounds__(256) void ws_standardize_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------ host side
-template <int KH, int KW, int S, int UPS, int KC, int TH, int TW>
+static ConvArgs fill_args(const DmhConv* d, int Hout, int Wout, int KC, int TH, int TW);
+
+template <int UPS, int KC, int TH, int TW, int WPE>
+static int launch_stream(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
+  using Cfg = ConvCfg<3, 3, 1, UPS, KC, TH, TW>;
+  ConvArgs a = fill_args(d, Hout, Wout, KC, TH, TW);
+  dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
+  hipLaunchKernelGGL((conv_stream_kernel<UPS, KC, TH, TW, WPE>), grid, dim3(256), Cfg::STREAM_LDS, st, a);
+  DMH_CHECK_LAUNCH("dmh_conv2d");
+  return DMH_OK;
+}
+
+template <int KH, int KW, int S, int UPS, int KC, int TH, int TW, int WPE = 2>
 static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   using Cfg = ConvCfg<KH, KW, S, UPS, KC, TH, TW>;
+  ConvArgs a = fill_args(d, Hout, Wout, KC, TH, TW);
+  dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
+  hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, S, UPS, KC, TH, TW, WPE>), grid, dim3(256), Cfg::LDS_BYTES, st, a);
+  DMH_CHECK_LAUNCH("dmh_conv2d");
+  return DMH_OK;
+}
+
+static ConvArgs fill_args(const DmhConv* d, int Hout, int Wout, int KC, int TH, int TW) {
   ConvArgs a;
   a.src0 = d->src0;
   a.src1 = d->src1;
@@ -344,10 +614,21 @@ static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   a.nch1 = cdiv(a.C1, KC);
   a.tilesX = cdiv(Wout, TW);
   a.tilesY = cdiv(Hout, TH);
-  dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
-  hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, S, UPS, KC, TH, TW>), grid, dim3(256), Cfg::LDS_BYTES, st, a);
-  DMH_CHECK_LAUNCH("dmh_conv2d");
-  return DMH_OK;
+  return a;
+}
+
+// 3x3 tiling variants (development knob DMH_CONV3_VARIANT, read once; the default is the measured best):
+//   0..3  conv_igemm_kernel   (KC,TH) = (32,16) (16,16) (32,8) (16,8)
+//   4, 5  conv_stream_kernel  (KC,TH) = (16,16) (16,8)
+#define DMH_CONV3_DEFAULT 3
+static int conv3_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DMH_CONV3_VARIANT");
+    v = e ? atoi(e) : DMH_CONV3_DEFAULT;
+    if (v < 0 || v > 5) v = DMH_CONV3_DEFAULT;
+  }
+  return v;
 }
 
 static int conv_out_dim(int in, int KH, int stride, int ups) {
@@ -356,15 +637,24 @@ static int conv_out_dim(int in, int KH, int stride, int ups) {
   return KH == 4 ? (in + 2 - 4) / 2 + 1 : in / 2;
 }
 
+static int conv_th(int KH, int stride) {
+  if (stride == 2) return 8;
+  if (KH == 3 && (conv3_variant() == 2 || conv3_variant() == 3 || conv3_variant() == 5)) return 8;
+  return 16;
+}
+
+static int conv_kc_v(int KH, int stride) {
+  if (KH == 3 && stride == 1 && conv3_variant() != 0 && conv3_variant() != 2) return 16;
+  return conv_kc(KH, stride);
+}
+
 extern "C" int dmh_conv_tiles(int Hout, int Wout, int KH, int stride) {
-  const int TH = (stride == 2) ? 8 : 16;
-  (void)KH;
-  return cdiv(Hout, TH) * cdiv(Wout, 16);
+  return cdiv(Hout, conv_th(KH, stride)) * cdiv(Wout, 16);
 }
 
 extern "C" int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW) {
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
-  const int KC = conv_kc(KH, stride);
+  const int KC = conv_kc_v(KH, stride);
   return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 64 * KC;
 }
 
@@ -374,11 +664,12 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   DMH_REQUIRE(KH == KW && (KH == 1 || KH == 2 || KH == 3 || KH == 4 || KH == 7),
               "dmh_pack_conv_weight: unsupported kernel %dx%d", KH, KW);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
-  const int KC = conv_kc(KH, stride);
+  const int KC = conv_kc_v(KH, stride);
   const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
   const int64_t total = dmh_conv_pack_floats(Cout, C0, C1, KH, KW);
+  const int layout = (KH == 3 && conv3_variant() >= 4) ? 1 : 0;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     w, wpack, Cout, C0, C1, KH, KW, KC, nch0, nch1, total);
+                     w, wpack, Cout, C0, C1, KH, KW, KC, nch0, nch1, layout, total);
   DMH_CHECK_LAUNCH("dmh_pack_conv_weight");
   return DMH_OK;
 }
@@ -397,6 +688,7 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
               "dmh_conv2d: input channels must be a multiple of 4 (got %d, %d)", d->C0, d->C1);
   DMH_REQUIRE(!(d->in_coef && d->src1), "dmh_conv2d: the GroupNorm prologue applies to a single source");
   DMH_REQUIRE(!(d->res_coef && !d->res), "dmh_conv2d: res_coef without res");
+  DMH_REQUIRE(d->Cout % 4 == 0, "dmh_conv2d: Cout must be a multiple of 4 (got %d)", d->Cout);
   hipStream_t st = (hipStream_t)stream;
   const int Hout = conv_out_dim(d->Hin, d->KH, d->stride, d->upsample2);
   const int Wout = conv_out_dim(d->Win, d->KW, d->stride, d->upsample2);
@@ -404,8 +696,24 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
   DMH_REQUIRE(d->KH == d->KW, "dmh_conv2d: non-square kernel");
   switch (key) {
     case 110: return launch_conv<1, 1, 1, 0, 32, 16, 16>(d, Hout, Wout, st);
-    case 310: return launch_conv<3, 3, 1, 0, 32, 16, 16>(d, Hout, Wout, st);
-    case 311: return launch_conv<3, 3, 1, 1, 32, 16, 16>(d, Hout, Wout, st);
+    case 310:
+      switch (conv3_variant()) {
+        case 1: return launch_conv<3, 3, 1, 0, 16, 16, 16, 3>(d, Hout, Wout, st);
+        case 2: return launch_conv<3, 3, 1, 0, 32, 8, 16, 3>(d, Hout, Wout, st);
+        case 3: return launch_conv<3, 3, 1, 0, 16, 8, 16, 4>(d, Hout, Wout, st);
+        case 4: return launch_stream<0, 16, 16, 16, 3>(d, Hout, Wout, st);
+        case 5: return launch_stream<0, 16, 8, 16, 4>(d, Hout, Wout, st);
+        default: return launch_conv<3, 3, 1, 0, 32, 16, 16, 2>(d, Hout, Wout, st);
+      }
+    case 311:
+      switch (conv3_variant()) {
+        case 1: return launch_conv<3, 3, 1, 1, 16, 16, 16, 3>(d, Hout, Wout, st);
+        case 2: return launch_conv<3, 3, 1, 1, 32, 8, 16, 3>(d, Hout, Wout, st);
+        case 3: return launch_conv<3, 3, 1, 1, 16, 8, 16, 4>(d, Hout, Wout, st);
+        case 4: return launch_stream<1, 16, 16, 16, 3>(d, Hout, Wout, st);
+        case 5: return launch_stream<1, 16, 8, 16, 4>(d, Hout, Wout, st);
+        default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
+      }
     case 710: return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);
     case 420: return launch_conv<4, 4, 2, 0, 16, 8, 16>(d, Hout, Wout, st);
     case 220:
