@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
     n1 = rng.randn((shi - slo, 2, 3), device)
     u1 = rng.uniform(shi - slo, device)
     q.put((rank, digest, (lo, hi), None if gi is None else gi[:, 0, 0, 0].tolist(),
-           None if gh is None else gh[:, 0, 0].tolist(), n1, u1))
+           None if gh is None else gh[:, 0, 0].tolist(), n1.tolist(), u1.tolist()))   # plain lists: no shm fds
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -59,8 +59,8 @@ def test_world2_gloo():
     assert gi0 == [0, 1, 2, 3, 4, 5] and gh0 == [0., 1., 2., 3., 4., 5.] and gi1 is None
     from dmhomo_amd import distributed as D
     full = D.SampleIndexedRng(7, range(0, 6), torch.device('cpu'))
-    assert torch.equal(torch.cat([n0, n1]), full.randn((6, 2, 3), torch.device('cpu')))
-    assert torch.equal(torch.cat([u0, u1]), full.uniform(6, torch.device('cpu')))
+    assert torch.equal(torch.tensor(n0 + n1), full.randn((6, 2, 3), torch.device('cpu')))
+    assert torch.equal(torch.tensor(u0 + u1), full.uniform(6, torch.device('cpu')))
 
 
 def test_shard_bounds_cover():
