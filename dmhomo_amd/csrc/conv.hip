@@ -26,21 +26,7 @@
 
 #include "common.h"
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-struct ConvArgs {
-  const float* src0;
-  const float* src1;
-  const float* wpack;
-  const float* bias;
-  const float* in_coef;
-  const float* res;
-  const float* res_coef;
-  float* out;
-  float* stats;
-  int B, Hin, Win, C0, C1, Cout, Hout, Wout;
-  int nch0, nch1, tilesX, tilesY;
-};
+#include "conv_args.h"
 
 template <int KH, int KW, int S, int UPS, int KC, int TH, int TW>
 struct ConvCfg {
@@ -65,23 +51,14 @@ struct ConvCfg {
 
 // ---- shared epilogue.  C/D layout of a 32x32 block: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // Each wave transposes its rows through a private LDS slab so that 16 lanes cover one pixel's 64 channels
-// with float4 accesses (bias / residual / stores all 16 B per lane).
+// with float4 accesses (bias / residual / stores all 16 B per lane): conv_args.h::EpilogueRows.
 template <int MB, int TH, int TW>
 __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[MB][2], const ConvArgs& p, float* lds, int b, int n0,
                                               int oy0, int ox0, int tile_in_sample) {
-  constexpr int EP = 68;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  const int c4 = lane & 15, rsub = lane >> 4;
-  const int chn = n0 + c4 * 4;
-  const bool cok = chn < p.Cout;  // Cout % 4 == 0
+  constexpr int EP = EpilogueRows::EP;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
   float* wl = lds + wave * (32 * EP);
-  float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), ra = bias, rb = bias;
-  if (cok && p.bias) bias = ld4(p.bias + chn);
-  if (cok && p.res_coef) {
-    ra = ld4(p.res_coef + (size_t)(b * 2 + 0) * p.Cout + chn);
-    rb = ld4(p.res_coef + (size_t)(b * 2 + 1) * p.Cout + chn);
-  }
-  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  EpilogueRows er(p, b, n0);
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
     __syncthreads();  // main loop (or the previous half) is done with this LDS
@@ -90,82 +67,9 @@ __device__ __forceinline__ void conv_epilogue(floatx16 (&acc)[MB][2], const Conv
 #pragma unroll
       for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * half) * EP + nb * 32 + l31] = acc[mb][nb][r];
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rr = i * 4 + rsub;
-      const int row = wave * (MB * 32) + mb * 32 + rr;
-      const int oy = oy0 + row / TW, ox = ox0 + row % TW;
-      if (cok && oy < p.Hout && ox < p.Wout) {
-        float4 val = ld4(wl + rr * EP + c4 * 4);
-        const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;
-        val.x += bias.x;
-        val.y += bias.y;
-        val.z += bias.z;
-        val.w += bias.w;
-        if (p.res) {
-          const float4 rv = ld4(p.res + o);
-          if (p.res_coef) {
-            val.x += silu_f(fmaf(ra.x, rv.x, rb.x));
-            val.y += silu_f(fmaf(ra.y, rv.y, rb.y));
-            val.z += silu_f(fmaf(ra.z, rv.z, rb.z));
-            val.w += silu_f(fmaf(ra.w, rv.w, rb.w));
-          } else {
-            val.x += rv.x;
-            val.y += rv.y;
-            val.z += rv.z;
-            val.w += rv.w;
-          }
-        }
-        st4(p.out + o, val);
-        s1.x += val.x;
-        s1.y += val.y;
-        s1.z += val.z;
-        s1.w += val.w;
-        s2.x = fmaf(val.x, val.x, s2.x);
-        s2.y = fmaf(val.y, val.y, s2.y);
-        s2.z = fmaf(val.z, val.z, s2.z);
-        s2.w = fmaf(val.w, val.w, s2.w);
-      }
-    }
+    er.template store_rows<TW>(p, wl, wave * (MB * 32) + mb * 32, oy0, ox0);
   }
-  if (p.stats) {
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      s1.x += __shfl_xor(s1.x, off);
-      s1.y += __shfl_xor(s1.y, off);
-      s1.z += __shfl_xor(s1.z, off);
-      s1.w += __shfl_xor(s1.w, off);
-      s2.x += __shfl_xor(s2.x, off);
-      s2.y += __shfl_xor(s2.y, off);
-      s2.z += __shfl_xor(s2.z, off);
-      s2.w += __shfl_xor(s2.w, off);
-    }
-    __syncthreads();  // every wave is done with its transpose slab: reuse LDS as the cross-wave scratch
-    float* red = lds;
-    if (lane < 16) {
-      float* q = red + (wave * 64 + c4 * 4) * 2;
-      q[0] = s1.x;
-      q[1] = s2.x;
-      q[2] = s1.y;
-      q[3] = s2.y;
-      q[4] = s1.z;
-      q[5] = s2.z;
-      q[6] = s1.w;
-      q[7] = s2.w;
-    }
-    __syncthreads();
-    if (tid < 64 && n0 + tid < p.Cout) {
-      float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        a0 += red[(w * 64 + tid) * 2 + 0];
-        a1 += red[(w * 64 + tid) * 2 + 1];
-      }
-      float* st = p.stats + ((size_t)(b * p.tilesX * p.tilesY + tile_in_sample) * p.Cout + n0 + tid) * 2;
-      st[0] = a0;
-      st[1] = a1;
-    }
-  }
+  er.write_stats(p, lds, tile_in_sample);
 }
 
 template <int KH, int KW, int S, int UPS, int KC, int TH, int TW, int WPE>
@@ -569,12 +473,10 @@ __global__ __launch_bounds__(256) void ws_standardize_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------ host side
-static ConvArgs fill_args(const DmhConv* d, int Hout, int Wout, int KC, int TH, int TW);
-
 template <int UPS, int KC, int TH, int TW, int WPE>
 static int launch_stream(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   using Cfg = ConvCfg<3, 3, 1, UPS, KC, TH, TW>;
-  ConvArgs a = fill_args(d, Hout, Wout, KC, TH, TW);
+  ConvArgs a = fill_conv_args(d, Hout, Wout, KC, TH, TW);
   dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
   hipLaunchKernelGGL((conv_stream_kernel<UPS, KC, TH, TW, WPE>), grid, dim3(256), Cfg::STREAM_LDS, st, a);
   DMH_CHECK_LAUNCH("dmh_conv2d");
@@ -584,49 +486,24 @@ static int launch_stream(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
 template <int KH, int KW, int S, int UPS, int KC, int TH, int TW, int WPE = 2>
 static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   using Cfg = ConvCfg<KH, KW, S, UPS, KC, TH, TW>;
-  ConvArgs a = fill_args(d, Hout, Wout, KC, TH, TW);
+  ConvArgs a = fill_conv_args(d, Hout, Wout, KC, TH, TW);
   dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
   hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, S, UPS, KC, TH, TW, WPE>), grid, dim3(256), Cfg::LDS_BYTES, st, a);
   DMH_CHECK_LAUNCH("dmh_conv2d");
   return DMH_OK;
 }
 
-static ConvArgs fill_args(const DmhConv* d, int Hout, int Wout, int KC, int TH, int TW) {
-  ConvArgs a;
-  a.src0 = d->src0;
-  a.src1 = d->src1;
-  a.wpack = d->wpack;
-  a.bias = d->bias;
-  a.in_coef = d->in_coef;
-  a.res = d->res;
-  a.res_coef = d->res_coef;
-  a.out = d->out;
-  a.stats = d->stats;
-  a.B = d->B;
-  a.Hin = d->Hin;
-  a.Win = d->Win;
-  a.C0 = d->C0;
-  a.C1 = d->src1 ? d->C1 : 0;
-  a.Cout = d->Cout;
-  a.Hout = Hout;
-  a.Wout = Wout;
-  a.nch0 = cdiv(a.C0, KC);
-  a.nch1 = cdiv(a.C1, KC);
-  a.tilesX = cdiv(Wout, TW);
-  a.tilesY = cdiv(Hout, TH);
-  return a;
-}
-
 // 3x3 tiling variants (development knob DMH_CONV3_VARIANT, read once; the default is the measured best):
 //   0..3  conv_igemm_kernel   (KC,TH) = (32,16) (16,16) (32,8) (16,8)
 //   4, 5  conv_stream_kernel  (KC,TH) = (16,16) (16,8)
-#define DMH_CONV3_DEFAULT 3
+//   6     conv_wino_kernel    Winograd F(2x2,3x3), 8x16 pixels x 64 cout per workgroup
+#define DMH_CONV3_DEFAULT 6
 static int conv3_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DMH_CONV3_VARIANT");
     v = e ? atoi(e) : DMH_CONV3_DEFAULT;
-    if (v < 0 || v > 5) v = DMH_CONV3_DEFAULT;
+    if (v < 0 || v > 6) v = DMH_CONV3_DEFAULT;
   }
   return v;
 }
@@ -639,7 +516,7 @@ static int conv_out_dim(int in, int KH, int stride, int ups) {
 
 static int conv_th(int KH, int stride) {
   if (stride == 2) return 8;
-  if (KH == 3 && (conv3_variant() == 2 || conv3_variant() == 3 || conv3_variant() == 5)) return 8;
+  if (KH == 3 && (conv3_variant() == 2 || conv3_variant() == 3 || conv3_variant() >= 5)) return 8;
   return 16;
 }
 
@@ -653,6 +530,7 @@ extern "C" int dmh_conv_tiles(int Hout, int Wout, int KH, int stride) {
 }
 
 extern "C" int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW) {
+  if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack_floats(Cout, C0, C1);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 64 * KC;
@@ -663,6 +541,7 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   DMH_REQUIRE(w && wpack && Cout > 0 && C0 > 0 && C1 >= 0, "dmh_pack_conv_weight: bad arguments");
   DMH_REQUIRE(KH == KW && (KH == 1 || KH == 2 || KH == 3 || KH == 4 || KH == 7),
               "dmh_pack_conv_weight: unsupported kernel %dx%d", KH, KW);
+  if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
@@ -703,6 +582,7 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 3: return launch_conv<3, 3, 1, 0, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 4: return launch_stream<0, 16, 16, 16, 3>(d, Hout, Wout, st);
         case 5: return launch_stream<0, 16, 8, 16, 4>(d, Hout, Wout, st);
+        case 6: return dmh_wino_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 0, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
     case 311:
@@ -712,6 +592,7 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 3: return launch_conv<3, 3, 1, 1, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 4: return launch_stream<1, 16, 16, 16, 3>(d, Hout, Wout, st);
         case 5: return launch_stream<1, 16, 8, 16, 4>(d, Hout, Wout, st);
+        case 6: return dmh_wino_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
     case 710: return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);

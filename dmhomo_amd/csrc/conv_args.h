@@ -1,0 +1,165 @@
+// Shared pieces of the convolution kernels: launch arguments and the float4 row epilogue.
+#pragma once
+#include "common.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+  const float* src0;
+  const float* src1;
+  const float* wpack;
+  const float* bias;
+  const float* in_coef;
+  const float* res;
+  const float* res_coef;
+  float* out;
+  float* stats;
+  int B, Hin, Win, C0, C1, Cout, Hout, Wout;
+  int nch0, nch1, tilesX, tilesY;
+};
+
+
+static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int KC, int TH, int TW) {
+  ConvArgs a;
+  a.src0 = d->src0;
+  a.src1 = d->src1;
+  a.wpack = d->wpack;
+  a.bias = d->bias;
+  a.in_coef = d->in_coef;
+  a.res = d->res;
+  a.res_coef = d->res_coef;
+  a.out = d->out;
+  a.stats = d->stats;
+  a.B = d->B;
+  a.Hin = d->Hin;
+  a.Win = d->Win;
+  a.C0 = d->C0;
+  a.C1 = d->src1 ? d->C1 : 0;
+  a.Cout = d->Cout;
+  a.Hout = Hout;
+  a.Wout = Wout;
+  a.nch0 = cdiv(a.C0, KC);
+  a.nch1 = cdiv(a.C1, KC);
+  a.tilesX = cdiv(Wout, TW);
+  a.tilesY = cdiv(Hout, TH);
+  return a;
+}
+
+
+// Winograd 3x3 path (conv_wino.hip)
+int64_t dmh_wino_pack_floats(int Cout, int C0, int C1);
+int dmh_wino_pack(const float* w, float* wpack, int Cout, int C0, int C1, hipStream_t st);
+int dmh_wino_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
+
+// Second half of every conv epilogue: an LDS slab holds rows = output pixels x 64 channels (pitch EP);
+// each wave turns 32 slab rows into NHWC float4 stores: + bias, + residual (optionally through
+// SiLU(a*res+b)), and accumulates the per-channel (sum, sum^2) that GroupNorm needs.  Lane l handles
+// channels 4*(l&15)..+3 of rows (l>>4) + 4*i.  Deterministic: fixed order, no atomics.
+struct EpilogueRows {
+  static constexpr int EP = 68;  // slab pitch in floats (64 + 4)
+  int b, n0, chn, c4, rsub;
+  bool cok;
+  float4 bias, ra, rb, s1, s2;
+
+  __device__ __forceinline__ EpilogueRows(const ConvArgs& p, int b_, int n0_) : b(b_), n0(n0_) {
+    const int lane = threadIdx.x & 63;
+    c4 = lane & 15;
+    rsub = lane >> 4;
+    chn = n0 + c4 * 4;
+    cok = chn < p.Cout;  // Cout % 4 == 0
+    bias = make_float4(0.f, 0.f, 0.f, 0.f);
+    ra = bias;
+    rb = bias;
+    s1 = bias;
+    s2 = bias;
+    if (cok && p.bias) bias = ld4(p.bias + chn);
+    if (cok && p.res_coef) {
+      ra = ld4(p.res_coef + (size_t)(b * 2 + 0) * p.Cout + chn);
+      rb = ld4(p.res_coef + (size_t)(b * 2 + 1) * p.Cout + chn);
+    }
+  }
+
+  // wl: this wave's 32 slab rows; row_base: tile-row index of slab row 0 (row -> pixel (row / TW, row % TW))
+  template <int TW>
+  __device__ __forceinline__ void store_rows(const ConvArgs& p, const float* wl, int row_base, int oy0, int ox0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = i * 4 + rsub;
+      const int row = row_base + rr;
+      const int oy = oy0 + row / TW, ox = ox0 + row % TW;
+      if (cok && oy < p.Hout && ox < p.Wout) {
+        float4 val = ld4(wl + rr * EP + c4 * 4);
+        const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;
+        val.x += bias.x;
+        val.y += bias.y;
+        val.z += bias.z;
+        val.w += bias.w;
+        if (p.res) {
+          const float4 rv = ld4(p.res + o);
+          if (p.res_coef) {
+            val.x += silu_f(fmaf(ra.x, rv.x, rb.x));
+            val.y += silu_f(fmaf(ra.y, rv.y, rb.y));
+            val.z += silu_f(fmaf(ra.z, rv.z, rb.z));
+            val.w += silu_f(fmaf(ra.w, rv.w, rb.w));
+          } else {
+            val.x += rv.x;
+            val.y += rv.y;
+            val.z += rv.z;
+            val.w += rv.w;
+          }
+        }
+        st4(p.out + o, val);
+        s1.x += val.x;
+        s1.y += val.y;
+        s1.z += val.z;
+        s1.w += val.w;
+        s2.x = fmaf(val.x, val.x, s2.x);
+        s2.y = fmaf(val.y, val.y, s2.y);
+        s2.z = fmaf(val.z, val.z, s2.z);
+        s2.w = fmaf(val.w, val.w, s2.w);
+      }
+    }
+  }
+
+  // cross-lane + cross-wave (4 waves, through LDS) reduction of the partials -> stats[b][tile][Cout][2]
+  __device__ __forceinline__ void write_stats(const ConvArgs& p, float* lds, int tile_in_sample) {
+    if (!p.stats) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      s1.x += __shfl_xor(s1.x, off);
+      s1.y += __shfl_xor(s1.y, off);
+      s1.z += __shfl_xor(s1.z, off);
+      s1.w += __shfl_xor(s1.w, off);
+      s2.x += __shfl_xor(s2.x, off);
+      s2.y += __shfl_xor(s2.y, off);
+      s2.z += __shfl_xor(s2.z, off);
+      s2.w += __shfl_xor(s2.w, off);
+    }
+    __syncthreads();  // every wave is done with the slab: reuse LDS as the cross-wave scratch
+    float* red = lds;
+    if (lane < 16) {
+      float* q = red + (wave * 64 + c4 * 4) * 2;
+      q[0] = s1.x;
+      q[1] = s2.x;
+      q[2] = s1.y;
+      q[3] = s2.y;
+      q[4] = s1.z;
+      q[5] = s2.z;
+      q[6] = s1.w;
+      q[7] = s2.w;
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + tid < p.Cout) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a0 += red[(w * 64 + tid) * 2 + 0];
+        a1 += red[(w * 64 + tid) * 2 + 1];
+      }
+      float* st = p.stats + ((size_t)(b * p.tilesX * p.tilesY + tile_in_sample) * p.Cout + n0 + tid) * 2;
+      st[0] = a0;
+      st[1] = a1;
+    }
+  }
+};
