@@ -13,12 +13,8 @@
 // SiLU(a*res+b)), 16 B-per-lane NHWC stores, and the per-tile (sum, sum^2) per output channel
 // that GroupNorm needs (fixed order, no atomics).
 //
-// Two main loops share that epilogue:
-//   conv_igemm_kernel   weight tile of each tap staged in LDS (double buffered, one barrier per tap);
-//                       used for 1x1, 7x7 and the strided variants
-//   conv_stream_kernel  3x3 hot path: B fragments stream straight from L2 into registers in
-//                       fragment-major order (one coalesced 1 KB load per wave-instruction, prefetched a
-//                       tap ahead), the input tile is double buffered => ONE barrier per channel chunk
+// conv_igemm_kernel serves 1x1, 7x7, 4x4/s2, 2x2/s2 (and 3x3 when DMH_CONV3_VARIANT selects it); the 3x3
+// stride-1 hot path defaults to the Winograd kernel of conv_wino.hip, which shares this epilogue.
 //
 // Replaces: F.conv2d of WeightStandardizedConv2d CFG:128, Downsample CFG:110-111 /
 // DDP:110-113, Upsample CFG:106-107, to_qkv / to_out / res_conv 1x1 convs, init_conv CFG:333.
@@ -45,8 +41,6 @@ struct ConvCfg {
   static constexpr int EPI_BYTES = 4 * 32 * 68 * 4;  // epilogue transpose scratch: 4 waves x 32 rows x (64+4)
   static constexpr int MAIN_BYTES = (IN_FLOATS + 2 * W_FLOATS) * 4;
   static constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
-  static constexpr int STREAM_MAIN = 2 * IN_FLOATS * 4;
-  static constexpr int STREAM_LDS = STREAM_MAIN > EPI_BYTES ? STREAM_MAIN : EPI_BYTES;
 };
 
 // ---- shared epilogue.  C/D layout of a 32x32 block: col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -141,27 +135,28 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
     const int Csrc = s1 ? p.C1 : p.C0;
     const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
     const bool cvalid = c < Csrc;
+    // every slot loads UNCONDITIONALLY from a clamped (always valid) address and is zeroed afterwards by the
+    // `inside` mask: no branch around a load, so the loads stay in flight under counted vmcnt waits
     inside = 0;
+    const int cc = cvalid ? c : 0;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int f = tid + i * 256;
       const int pix = f / C4;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pix < IN_PIX && cvalid) {
-        const int hy = pix / IN_W, hx = pix % IN_W;
-        const int yy = iy0 + hy, xx = ix0 + hx;
-        if (yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim) {
-          const int sy = UPS ? (yy >> 1) : yy, sx = UPS ? (xx >> 1) : xx;
-          v[i] = ld4(src + ((size_t)(b * p.Hin + sy) * p.Win + sx) * Csrc + c);
-          inside |= 1u << i;
-        }
-      }
+      const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
+      const int hy = pixc / IN_W, hx = pixc % IN_W;
+      const int yy = iy0 + hy, xx = ix0 + hx;
+      const bool ok = cvalid && pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
+      const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
+      const int sy = UPS ? (yc >> 1) : yc, sx = UPS ? (xc >> 1) : xc;
+      v[i] = ld4(src + ((size_t)(b * p.Hin + sy) * p.Win + sx) * Csrc + cc);
+      inside |= (ok ? 1u : 0u) << i;
     }
     ca = make_float4(1.f, 1.f, 1.f, 1.f);
     cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.in_coef != nullptr && !s1 && cvalid) {
-      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + c);
-      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + c);
+    if (p.in_coef != nullptr && !s1) {  // wave-uniform condition; clamped channel for the padded tail
+      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + cc);
+      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + cc);
     }
   };
   issue_chunk_loads(0);
@@ -176,7 +171,9 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
       const int pix = f / C4;
       if (pix < IN_PIX) {
         float4 x = v[i];
-        if (pro && ((inside >> i) & 1u)) {  // padding stays exactly zero: it pads the ACTIVATED tensor
+        if (!((inside >> i) & 1u)) {
+          x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly zero: it pads the ACTIVATED tensor
+        } else if (pro) {
           x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
           x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
           x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
@@ -240,193 +237,17 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
   conv_epilogue<MB, TH, TW>(acc, p, lds, b, n0, oy0, ox0, tile_in_sample);
 }
 
-// ------------------------------------------------------------------------------------------------
-// 3x3 hot path.  Same tiling, but the weight (B) fragments never touch LDS: the packed image is
-// fragment-major ([chunk][tap][k8][nb][lane][4]) so each wave-instruction is one coalesced 1 KB load that
-// lands directly in the MFMA operand registers, issued a whole tap (>= 2048 matrix cycles) ahead; the four
-// waves of a workgroup hit the same lines (L1/L2).  The input tile is double buffered, so the only
-// workgroup barrier left is the one that publishes the next channel chunk.
-template <int UPS, int KC, int TH, int TW, int WPE>
-__global__ __launch_bounds__(256, WPE) void conv_stream_kernel(ConvArgs p) {
-  using Cfg = ConvCfg<3, 3, 1, UPS, KC, TH, TW>;
-  constexpr int MB = Cfg::MB, IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, KCP = Cfg::KCP, C4 = Cfg::C4;
-  constexpr int NLOAD = Cfg::NLOAD, NTAPS = 9, K8 = KC / 8, NB4 = K8 * 2;  // NB4 float4 of B per lane per tap
-
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int half = lane >> 5;
-  const int l31 = lane & 31;
-
-  int t = blockIdx.x;
-  const int tx = t % p.tilesX;
-  t /= p.tilesX;
-  const int ty = t % p.tilesY;
-  const int b = t / p.tilesY;
-  const int nt = blockIdx.y;
-  const int n0 = nt * 64;
-  const int tile_in_sample = ty * p.tilesX + tx;
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-  const int Hlim = UPS ? p.Hin * 2 : p.Hin;
-  const int Wlim = UPS ? p.Win * 2 : p.Win;
-
-  int arow[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int r = wave * (MB * 32) + mb * 32 + l31;
-    arow[mb] = ((r / TW) * IN_W + (r % TW)) * KCP + half * 4;
-  }
-
-  floatx16 acc[MB][2];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
-
-  const int nchunks = p.nch0 + p.nch1;
-  const float* wbase = p.wpack + (size_t)nt * nchunks * NTAPS * 64 * KC + lane * 4;
-  const int c4 = tid % C4;
-
-  float4 v[NLOAD];
-  float4 ca, cb;
-  unsigned inside;
-  auto issue_chunk_loads = [&](int ch) {
-    const bool s1 = ch >= p.nch0;
-    const float* src = s1 ? p.src1 : p.src0;
-    const int Csrc = s1 ? p.C1 : p.C0;
-    const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
-    const bool cvalid = c < Csrc;
-    inside = 0;
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const int f = tid + i * 256;
-      const int pix = f / C4;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pix < IN_PIX && cvalid) {
-        const int hy = pix / IN_W, hx = pix % IN_W;
-        const int yy = iy0 + hy, xx = ix0 + hx;
-        if (yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim) {
-          const int sy = UPS ? (yy >> 1) : yy, sx = UPS ? (xx >> 1) : xx;
-          v[i] = ld4(src + ((size_t)(b * p.Hin + sy) * p.Win + sx) * Csrc + c);
-          inside |= 1u << i;
-        }
-      }
-    }
-    ca = make_float4(1.f, 1.f, 1.f, 1.f);
-    cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.in_coef != nullptr && !s1 && cvalid) {
-      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + c);
-      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + c);
-    }
-  };
-  auto write_chunk = [&](int ch) {  // registers -> (prologue SiLU(a*x+b)) -> LDS buffer ch & 1
-    const bool pro = (p.in_coef != nullptr) && ch < p.nch0;
-    float* dst = lds + (ch & 1) * Cfg::IN_FLOATS;
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const int f = tid + i * 256;
-      const int pix = f / C4;
-      if (pix < IN_PIX) {
-        float4 x = v[i];
-        if (pro && ((inside >> i) & 1u)) {  // padding stays exactly zero: it pads the ACTIVATED tensor
-          x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
-          x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
-          x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
-          x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
-        }
-        st4(dst + pix * KCP + c4 * 4, x);
-      }
-    }
-  };
-
-  float4 bn[NB4];
-#pragma unroll
-  for (int i = 0; i < NB4; ++i) bn[i] = ld4(wbase + (size_t)i * 256);
-  issue_chunk_loads(0);
-  write_chunk(0);
-  __syncthreads();
-
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const float* in_tile = lds + (ch & 1) * Cfg::IN_FLOATS;
-#pragma unroll
-    for (int tap = 0; tap < NTAPS; ++tap) {
-      float4 bc[NB4];
-#pragma unroll
-      for (int i = 0; i < NB4; ++i) bc[i] = bn[i];
-      {
-        int nch = ch, ntap = tap + 1;
-        if (ntap == NTAPS) {
-          ntap = 0;
-          nch = ch + 1;
-        }
-        if (nch < nchunks) {
-          const float* wsrc = wbase + ((size_t)nch * NTAPS + ntap) * 64 * KC;
-#pragma unroll
-          for (int i = 0; i < NB4; ++i) bn[i] = ld4(wsrc + (size_t)i * 256);
-        }
-        if (tap == NTAPS - 1 && ch + 1 < nchunks) issue_chunk_loads(ch + 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);  // prefetches stay above the matrix phase
-      const float* at = in_tile + ((tap / 3) * IN_W + (tap % 3)) * KCP;
-#pragma unroll
-      for (int k8 = 0; k8 < K8; ++k8) {
-        float4 a[MB];
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) a[mb] = ld4(at + arow[mb] + k8 * 8);
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            const float4 bq = bc[k8 * 2 + nb];
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].x, bq.x, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].y, bq.y, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].z, bq.z, acc[mb][nb], 0, 0, 0);
-            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb].w, bq.w, acc[mb][nb], 0, 0, 0);
-          }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ch + 1 < nchunks) {
-      write_chunk(ch + 1);  // other buffer: nobody reads it until the barrier below
-      __syncthreads();
-    }
-  }
-  conv_epilogue<MB, TH, TW>(acc, p, lds, b, n0, oy0, ox0, tile_in_sample);
-}
-
 // ------------------------------------------------------------------------------ weight packing
-// layout 0: [ntile][chunk][tap][col 64][k KC]           (weight tile copied into LDS)
-// layout 1: [ntile][chunk][tap][k8][nb][lane 64][4]      (fragment-major: lane = half*32 + col%32 holds
-//           k = k8*8 + half*4 + e of column nb*32 + col%32 — exactly one MFMA B operand quad)
+// [ntile][chunk][tap][col 64][k KC]: one (chunk, tap) weight tile is a linear copy into LDS
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int C0,
-                                        int C1, int KH, int KW, int KC, int nch0, int nch1, int layout,
-                                        int64_t total) {
+                                        int C1, int KH, int KW, int KC, int nch0, int nch1, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int64_t r = idx;
-  int k, j;
-  if (layout == 0) {
-    k = r % KC;
-    r /= KC;
-    j = r % 64;
-    r /= 64;
-  } else {
-    const int e = r % 4;
-    r /= 4;
-    const int lane = r % 64;
-    r /= 64;
-    const int nb = r % 2;
-    r /= 2;
-    const int k8 = r % (KC / 8);
-    r /= (KC / 8);
-    k = k8 * 8 + (lane >> 5) * 4 + e;
-    j = nb * 32 + (lane & 31);
-  }
+  const int k = r % KC;
+  r /= KC;
+  const int j = r % 64;
+  r /= 64;
   const int tap = r % (KH * KW);
   r /= (KH * KW);
   const int ch = r % (nch0 + nch1);
@@ -473,16 +294,6 @@ __global__ __launch_bounds__(256) void ws_standardize_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------------------ host side
-template <int UPS, int KC, int TH, int TW, int WPE>
-static int launch_stream(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
-  using Cfg = ConvCfg<3, 3, 1, UPS, KC, TH, TW>;
-  ConvArgs a = fill_conv_args(d, Hout, Wout, KC, TH, TW);
-  dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
-  hipLaunchKernelGGL((conv_stream_kernel<UPS, KC, TH, TW, WPE>), grid, dim3(256), Cfg::STREAM_LDS, st, a);
-  DMH_CHECK_LAUNCH("dmh_conv2d");
-  return DMH_OK;
-}
-
 template <int KH, int KW, int S, int UPS, int KC, int TH, int TW, int WPE = 2>
 static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   using Cfg = ConvCfg<KH, KW, S, UPS, KC, TH, TW>;
@@ -495,7 +306,6 @@ static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
 
 // 3x3 tiling variants (development knob DMH_CONV3_VARIANT, read once; the default is the measured best):
 //   0..3  conv_igemm_kernel   (KC,TH) = (32,16) (16,16) (32,8) (16,8)
-//   4, 5  conv_stream_kernel  (KC,TH) = (16,16) (16,8)
 //   6     conv_wino_kernel    Winograd F(2x2,3x3), 8x16 pixels x 64 cout per workgroup
 #define DMH_CONV3_DEFAULT 6
 static int conv3_variant() {
@@ -503,7 +313,7 @@ static int conv3_variant() {
   if (v < 0) {
     const char* e = getenv("DMH_CONV3_VARIANT");
     v = e ? atoi(e) : DMH_CONV3_DEFAULT;
-    if (v < 0 || v > 6) v = DMH_CONV3_DEFAULT;
+    if (v < 0 || v > 6 || v == 4 || v == 5) v = DMH_CONV3_DEFAULT;
   }
   return v;
 }
@@ -546,9 +356,8 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   const int KC = conv_kc_v(KH, stride);
   const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
   const int64_t total = dmh_conv_pack_floats(Cout, C0, C1, KH, KW);
-  const int layout = (KH == 3 && conv3_variant() >= 4) ? 1 : 0;
   hipLaunchKernelGGL(pack_conv_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     w, wpack, Cout, C0, C1, KH, KW, KC, nch0, nch1, layout, total);
+                     w, wpack, Cout, C0, C1, KH, KW, KC, nch0, nch1, total);
   DMH_CHECK_LAUNCH("dmh_pack_conv_weight");
   return DMH_OK;
 }
@@ -580,8 +389,6 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 1: return launch_conv<3, 3, 1, 0, 16, 16, 16, 3>(d, Hout, Wout, st);
         case 2: return launch_conv<3, 3, 1, 0, 32, 8, 16, 3>(d, Hout, Wout, st);
         case 3: return launch_conv<3, 3, 1, 0, 16, 8, 16, 4>(d, Hout, Wout, st);
-        case 4: return launch_stream<0, 16, 16, 16, 3>(d, Hout, Wout, st);
-        case 5: return launch_stream<0, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 0, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
@@ -590,8 +397,6 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 1: return launch_conv<3, 3, 1, 1, 16, 16, 16, 3>(d, Hout, Wout, st);
         case 2: return launch_conv<3, 3, 1, 1, 32, 8, 16, 3>(d, Hout, Wout, st);
         case 3: return launch_conv<3, 3, 1, 1, 16, 8, 16, 4>(d, Hout, Wout, st);
-        case 4: return launch_stream<1, 16, 16, 16, 3>(d, Hout, Wout, st);
-        case 5: return launch_stream<1, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }

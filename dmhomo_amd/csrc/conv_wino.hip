@@ -13,6 +13,8 @@
 // the output transform is register-local; results go through the shared float4 row epilogue
 // (+bias, +residual, GroupNorm partials).  Dual-source (fused torch.cat) and nearest-x2 upsampled
 // inputs are handled in the halo gather exactly as in conv.hip.
+#include <stdlib.h>
+
 #include "conv_args.h"
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -27,6 +29,26 @@ constexpr int NLOAD = (IN_PIX * 4 + 255) / 256;    // 3 float4 per thread per ch
 constexpr int PD = 4;                              // weight prefetch depth in positions
 }  // namespace
 
+typedef float float2v __attribute__((ext_vector_type(2)));
+struct f4 {  // a float4 as two packed pairs: + and - compile to v_pk_add_f32 (two lane-ops per instruction)
+  float2v lo, hi;
+};
+__device__ __forceinline__ f4 ldf4(const float* p) {
+  const float4 t = ld4(p);
+  f4 r;
+  r.lo = float2v{t.x, t.y};
+  r.hi = float2v{t.z, t.w};
+  return r;
+}
+__device__ __forceinline__ void stf4(float* p, const f4& v) { st4(p, make_float4(v.lo.x, v.lo.y, v.hi.x, v.hi.y)); }
+__device__ __forceinline__ f4 operator+(const f4& a, const f4& b) { return f4{a.lo + b.lo, a.hi + b.hi}; }
+__device__ __forceinline__ f4 operator-(const f4& a, const f4& b) { return f4{a.lo - b.lo, a.hi - b.hi}; }
+
+// NOTE on instruction economy: on gfx950 the fp32 MFMA runs at the fp32 VALU rate and does not overlap with
+// VALU work of the same SIMD (measured: MFMA-busy + VALU-busy + LDS issue ~ 100 %), so every vector
+// instruction in the chunk loop is paid in matrix throughput.  Everything chunk-invariant (halo pixel
+// offsets, validity mask, LDS offsets of the transform items) is therefore computed once, global loads use
+// a uniform (scalar) base + a precomputed 32-bit lane offset, and the transforms use packed fp32 adds.
 template <int UPS>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -35,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;  // 2 (tiles) x 2 (cout) waves
   const int j16 = lane & 15, kq = lane >> 4;
 
@@ -48,9 +70,60 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
   const int n0 = nt * 64;
   const int tile_in_sample = ty0 * p.tilesX + tx0;
   const int oy0 = ty0 * TH, ox0 = tx0 * TW;
-  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
-  const int Hlim = UPS ? p.Hin * 2 : p.Hin;
-  const int Wlim = UPS ? p.Win * 2 : p.Win;
+
+#ifdef DMH_STAMPS
+  // diagnostic build only (make stamps): per-wave cycle totals of each phase, written over this tile's stats slot
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev, t_now;
+#define STAMP(i)                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  tk[i] += t_now - t_prev;                                                       \
+  t_prev = t_now;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+  const unsigned long long t_begin = t_prev;
+#else
+#define STAMP(i)
+#endif
+
+  // ---- chunk-invariant staging state: 3 halo slots per thread (pixel, channel quad c4)
+  const int c4 = tid & 3;
+  int poff[NLOAD];      // clamped source pixel index (within the whole tensor), always addressable
+  unsigned inside = 0;  // bit i: slot i is image data (not zero padding / not beyond the tile)
+  {
+    const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+    const int Hlim = UPS ? p.Hin * 2 : p.Hin;
+    const int Wlim = UPS ? p.Win * 2 : p.Win;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int pix = (tid + i * 256) >> 2;
+      const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
+      const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
+      const bool ok = pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
+      const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
+      const int sy = UPS ? (yc >> 1) : yc, sx = UPS ? (xc >> 1) : xc;
+      poff[i] = (b * p.Hin + sy) * p.Win + sx;
+      inside |= (ok ? 1u : 0u) << i;
+    }
+  }
+  // LDS offsets of this thread's two transform items (tile, channel quad cq, row xi): chunk-invariant too
+  int rd_a[2], rd_b[2], wr_v[2];
+  float sgn[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + it * 256;
+    const int tile = item & 31, cq = (item >> 5) & 3, xi = item >> 7;
+    const int ty = tile >> 3, tx = tile & 7;
+    // rows of d that enter row xi of B^T d:  xi0: d0-d2, xi1: d1+d2, xi2: d2-d1, xi3: d1-d3
+    const int ra_ = (xi == 0) ? 0 : (xi == 2 ? 2 : 1);
+    const int rb_ = (xi == 0 || xi == 1) ? 2 : (xi == 2 ? 1 : 3);
+    sgn[it] = (xi == 1) ? 1.f : -1.f;
+    rd_a[it] = ((2 * ty + ra_) * IN_W + 2 * tx) * RAWP + cq * 4;
+    rd_b[it] = ((2 * ty + rb_) * IN_W + 2 * tx) * RAWP + cq * 4;
+    wr_v[it] = (((xi * 4) * 4 + cq) * NT + tile) * 4;  // position 4*xi + nu, k-quarter cq
+  }
+  const int wr_raw0 = (tid >> 2) * RAWP + c4 * 4;  // slot i lives 64 pixels further: + i * 64 * RAWP
 
   floatx4 acc[16][2];
 #pragma unroll
@@ -61,113 +134,94 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
       for (int r = 0; r < 4; ++r) acc[q][nb][r] = 0.f;
 
   const int nchunks = p.nch0 + p.nch1;
-  // packed U: [nt][chunk][pos 16][nb4 4][lane 64][4]; this wave's two 16-channel blocks are nb4 = 2*wn, 2*wn+1
-  const float* wbase = p.wpack + (size_t)nt * nchunks * (16 * 4 * 256) + (wn * 2) * 256 + lane * 4;
+  // packed U: [nt][chunk][pos 16][nb4 4][lane 64][4]; this wave's two 16-channel blocks are nb4 = 2*wn, 2*wn+1.
+  // uniform (scalar) base + lane offset => saddr addressing, pointer bumps on the scalar unit
+  const float* wu = p.wpack + (size_t)nt * nchunks * (16 * 4 * 256) + (wn * 2) * 256;
+  const int wlane = lane * 4;
+  const float* va = V + (kq * NT + wm * 16 + j16) * 4;
 
-  // ---- input halo: global -> registers
-  const int c4 = tid & 3;
   float4 v[NLOAD];
-  float4 ca, cb;
-  unsigned inside;
+  float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
   auto issue_chunk_loads = [&](int ch) {
     const bool s1 = ch >= p.nch0;
-    const float* src = s1 ? p.src1 : p.src0;
+    const float* src = s1 ? p.src1 : p.src0;  // uniform
     const int Csrc = s1 ? p.C1 : p.C0;
-    const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
-    const bool cvalid = c < Csrc;
-    inside = 0;
+    const int cbase = (s1 ? ch - p.nch0 : ch) * KC;
+    const int cc = (cbase + c4 * 4 < Csrc) ? cbase + c4 * 4 : 0;  // clamped for the padded tail of the last chunk
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const int pix = (tid + i * 256) >> 2;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pix < IN_PIX && cvalid) {
-        const int hy = pix / IN_W, hx = pix % IN_W;
-        const int yy = iy0 + hy, xx = ix0 + hx;
-        if (yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim) {
-          const int sy = UPS ? (yy >> 1) : yy, sx = UPS ? (xx >> 1) : xx;
-          v[i] = ld4(src + ((size_t)(b * p.Hin + sy) * p.Win + sx) * Csrc + c);
-          inside |= 1u << i;
-        }
-      }
-    }
-    ca = make_float4(1.f, 1.f, 1.f, 1.f);
-    cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.in_coef != nullptr && !s1 && cvalid) {
-      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + c);
-      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + c);
+    for (int i = 0; i < NLOAD; ++i) v[i] = ld4(src + (size_t)poff[i] * Csrc + cc);
+    if (p.in_coef != nullptr && !s1) {
+      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + cc);
+      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + cc);
     }
   };
 
-  // ---- weight (B operand) pipeline: PD positions in flight, refilled in place right after use
   float4 bq[PD][2];
-  auto load_b = [&](int slot, int ch, int pos) {
-    const float* wsrc = wbase + ((size_t)ch * 16 + pos) * (4 * 256);
-    bq[slot][0] = ld4(wsrc);
-    bq[slot][1] = ld4(wsrc + 256);
-  };
-#pragma unroll
-  for (int q = 0; q < PD; ++q) load_b(q, 0, q);
   issue_chunk_loads(0);
 
   for (int ch = 0; ch < nchunks; ++ch) {
-    // ---- 1. registers -> (prologue SiLU(a*x+b)) -> raw LDS tile.  The previous chunk's transform finished
-    //         reading `raw` before the barrier that preceded its matrix phase.
+    // ---- 1. registers -> (prologue SiLU(a*x+b)) -> raw LDS tile
     {
-      const bool pro = (p.in_coef != nullptr) && ch < p.nch0;
+      const bool s1 = ch >= p.nch0;
+      const bool pro = (p.in_coef != nullptr) && !s1;
+      const int Csrc = s1 ? p.C1 : p.C0;
+      const bool cvalid = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4 < Csrc;
+      const unsigned m = cvalid ? inside : 0u;
 #pragma unroll
       for (int i = 0; i < NLOAD; ++i) {
-        const int pix = (tid + i * 256) >> 2;
-        if (pix < IN_PIX) {
+        if (i < NLOAD - 1 || ((tid + i * 256) >> 2) < IN_PIX) {
           float4 x = v[i];
-          if (pro && ((inside >> i) & 1u)) {  // padding stays exactly zero: it pads the ACTIVATED tensor
+          if (!((m >> i) & 1u)) {
+            x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly zero: it pads the ACTIVATED tensor
+          } else if (pro) {
             x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
             x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
             x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
             x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
           }
-          st4(raw + pix * RAWP + c4 * 4, x);
+          st4(raw + wr_raw0 + i * (64 * RAWP), x);
         }
       }
     }
+    // first PD weight positions of THIS chunk: issued only now, so that the vmcnt wait of the raw write above
+    // covered nothing but the halo loads (refills never cross a chunk boundary)
+    const float* wch = wu + (size_t)ch * (16 * 4 * 256);
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+      bq[q][0] = ld4(wch + q * 1024 + wlane);
+      bq[q][1] = ld4(wch + q * 1024 + 256 + wlane);
+    }
+    STAMP(0)          // raw write (+ prologue)
     __syncthreads();  // raw published; every wave has also left the previous matrix phase (V is free)
-    if (ch + 1 < nchunks) issue_chunk_loads(ch + 1);  // travels behind the transform + matrix phase
+    STAMP(1)          // barrier 1
+    // next chunk's halo (on the last chunk: a harmless re-load of itself — an UNCONDITIONAL issue lets hipcc
+    // count vmcnt exactly instead of draining these loads at the first weight wait of the matrix phase)
+    issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
 
-    // ---- 2. input transform V = B^T d B: work item = (tile, channel quad, row xi), two per thread
+    // ---- 2. input transform V = B^T d B, two items per thread, packed fp32 adds
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      const int item = tid + it * 256;
-      const int tile = item & 31, cq = (item >> 5) & 3, xi = item >> 7;
-      const int ty = tile >> 3, tx = tile & 7;
-      // rows of d that enter row xi of B^T d:  xi0: d0-d2, xi1: d1+d2, xi2: d2-d1, xi3: d1-d3
-      const int ra_ = (xi == 0) ? 0 : (xi == 2 ? 2 : 1);
-      const int rb_ = (xi == 0 || xi == 1) ? 2 : (xi == 2 ? 1 : 3);
-      const float sgn = (xi == 1) ? 1.f : -1.f;
-      const float* pa = raw + ((2 * ty + ra_) * IN_W + 2 * tx) * RAWP + cq * 4;
-      const float* pb = raw + ((2 * ty + rb_) * IN_W + 2 * tx) * RAWP + cq * 4;
-      float4 w[4];
+      const float* pa = raw + rd_a[it];
+      const float* pb = raw + rd_b[it];
+      const float2v sg = float2v{sgn[it], sgn[it]};
+      f4 w[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float4 da = ld4(pa + c * RAWP), db = ld4(pb + c * RAWP);
-        w[c].x = fmaf(sgn, db.x, da.x);
-        w[c].y = fmaf(sgn, db.y, da.y);
-        w[c].z = fmaf(sgn, db.z, da.z);
-        w[c].w = fmaf(sgn, db.w, da.w);
+        const f4 da = ldf4(pa + c * RAWP), db = ldf4(pb + c * RAWP);
+        w[c].lo = da.lo + sg * db.lo;
+        w[c].hi = da.hi + sg * db.hi;
       }
-      float4 o0, o1, o2, o3;  // V[xi][0..3] = w0-w2, w1+w2, w2-w1, w1-w3
-      o0.x = w[0].x - w[2].x; o0.y = w[0].y - w[2].y; o0.z = w[0].z - w[2].z; o0.w = w[0].w - w[2].w;
-      o1.x = w[1].x + w[2].x; o1.y = w[1].y + w[2].y; o1.z = w[1].z + w[2].z; o1.w = w[1].w + w[2].w;
-      o2.x = w[2].x - w[1].x; o2.y = w[2].y - w[1].y; o2.z = w[2].z - w[1].z; o2.w = w[2].w - w[1].w;
-      o3.x = w[1].x - w[3].x; o3.y = w[1].y - w[3].y; o3.z = w[1].z - w[3].z; o3.w = w[1].w - w[3].w;
-      float* vo = V + (((xi * 4) * 4 + cq) * NT + tile) * 4;  // position 4*xi + nu, k-quarter cq
-      st4(vo, o0);
-      st4(vo + 1 * (4 * NT * 4), o1);
-      st4(vo + 2 * (4 * NT * 4), o2);
-      st4(vo + 3 * (4 * NT * 4), o3);
+      float* vo = V + wr_v[it];  // V[xi][0..3] = w0-w2, w1+w2, w2-w1, w1-w3
+      stf4(vo, w[0] - w[2]);
+      stf4(vo + 1 * (4 * NT * 4), w[1] + w[2]);
+      stf4(vo + 2 * (4 * NT * 4), w[2] - w[1]);
+      stf4(vo + 3 * (4 * NT * 4), w[1] - w[3]);
     }
+    STAMP(2)          // input transform
     __syncthreads();  // V published
+    STAMP(3)          // barrier 2
 
     // ---- 3. matrix phase: M_pos[tile][cout] += V_pos[tile][k] * U_pos[k][cout], 16 positions
-    const float* va = V + (kq * NT + wm * 16 + j16) * 4;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const float4 a = ld4(va + q * (4 * NT * 4));
@@ -180,17 +234,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
       acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc[q][1], 0, 0, 0);
       acc[q][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc[q][0], 0, 0, 0);
       acc[q][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc[q][1], 0, 0, 0);
-      // refill this slot with the position PD ahead (wraps into the next chunk)
-      {
-        int nq = q + PD, nch = ch;
-        if (nq >= 16) {
-          nq -= 16;
-          nch = ch + 1;
-        }
-        if (nch < nchunks) load_b(q % PD, nch, nq);
+      if (q + PD < 16) {  // refill this slot with the position PD ahead
+        bq[q % PD][0] = ld4(wch + (q + PD) * 1024 + wlane);
+        bq[q % PD][1] = ld4(wch + (q + PD) * 1024 + 256 + wlane);
       }
       __builtin_amdgcn_sched_barrier(0);  // keep the refill load here, not next to its consumer
     }
+    STAMP(4)  // matrix phase
   }
 
   // ---- output transform Y = A^T M A, register-local: lane holds M_pos[tile = wm*16 + kq*4 + r][cout = .. + j16]
@@ -210,18 +260,29 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
         tt[0][nu] = m0 + m1 + m2;
         tt[1][nu] = m1 - m2 - m3;
       }
+      float* sl = lds + ((2 * ty) * TW + 2 * tx) * EP + col;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int prow = (2 * ty + i) * TW + 2 * tx;
-        lds[prow * EP + col] = tt[i][0] + tt[i][1] + tt[i][2];
-        lds[(prow + 1) * EP + col] = tt[i][1] - tt[i][2] - tt[i][3];
+        sl[(i * TW) * EP] = tt[i][0] + tt[i][1] + tt[i][2];
+        sl[(i * TW + 1) * EP] = tt[i][1] - tt[i][2] - tt[i][3];
       }
     }
   }
   __syncthreads();
   EpilogueRows er(p, b, n0);
   er.template store_rows<TW>(p, lds + wave * (32 * EP), wave * 32, oy0, ox0);
+#ifdef DMH_STAMPS
+  STAMP(5)  // output transform + row epilogue
+  if (p.stats && lane == 0 && nt == 0) {
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(
+                                p.stats + ((size_t)(b * p.tilesX * p.tilesY + tile_in_sample) * p.Cout) * 2) + wave * 8;
+    for (int i = 0; i < 6; ++i) d[i] = tk[i];
+    d[6] = t_now - t_begin;
+    d[7] = t_begin;
+  }
+#else
   er.write_stats(p, lds, tile_in_sample);
+#endif
 }
 
 // transformed weights U = G g G^T in fragment-major order [nt][chunk][pos][nb4][lane][4]:
