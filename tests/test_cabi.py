@@ -35,9 +35,11 @@ def test_library_loads_and_exports_every_symbol():
 def test_pure_host_entry_points():
     from dmhomo_amd import _lib
     lib = _lib.lib()
-    # packed size: ceil(Cout/64) * chunks * taps * 64 * KC
-    assert lib.dmh_conv_pack_floats(64, 64, 0, 3, 3) == 1 * 2 * 9 * 64 * 32
-    assert lib.dmh_conv_pack_floats(512, 512, 256, 3, 3) == 8 * (16 + 8) * 9 * 64 * 32
+    # 3x3: Winograd image = ceil(Cout/64) * chunks(16 ch) * 16 positions * 64 cout * 16 k  (default tiling);
+    # implicit-GEMM image = ceil(Cout/64) * chunks * 9 taps * 64 * KC when DMH_CONV3_VARIANT selects it
+    assert lib.dmh_conv_pack_floats(64, 64, 0, 3, 3) in (1 * 4 * 16 * 64 * 16, 1 * 2 * 9 * 64 * 32)
+    assert lib.dmh_conv_pack_floats(512, 512, 256, 3, 3) in (8 * (32 + 16) * 16 * 64 * 16, 8 * (16 + 8) * 9 * 64 * 32)
+    assert lib.dmh_conv_pack_floats(384, 64, 0, 1, 1) == 6 * 2 * 1 * 64 * 32
     assert lib.dmh_conv_pack_floats(64, 12, 0, 7, 7) == 1 * 1 * 49 * 64 * 16
     assert lib.dmh_conv_pack_floats(128, 64, 0, 4, 4) == 2 * 4 * 16 * 64 * 16
     assert lib.dmh_conv_tiles(128, 128, 3, 1) in (64, 128)      # 16x16 or 8x16 output tiles (3x3 tiling variant)
