@@ -81,20 +81,27 @@ class Unet(nn.Module):
             return torch.zeros((batch,), device=device, dtype=torch.uint8)
         return (self.rng.uniform(batch, device) < prob).to(torch.uint8)
 
-    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None):
-        """rows [rep*B + b]: sample b under class-keep mask keeps[rep] -> (len(keeps)*B, out_dim, H, W)."""
+    def _stem(self, x, rgb_flow, mask):
+        """cat((x, rgb_flow*mask)) -> NHWC -> init_conv: identical for the cond and the null pass (CFG:430-432)."""
         if not x.is_cuda:
             raise RuntimeError('dmhomo_amd.Unet runs on the GPU only (HIP kernels); move the inputs with .cuda()')
         eng = self._engine
         eng.ensure_prepared()
-        x = x.to(torch.float32).contiguous()
-        rgb_flow = rgb_flow.to(torch.float32).contiguous()
-        mask = mask.to(torch.float32).contiguous()
+        xin = ops.assemble_input(x.to(torch.float32).contiguous(), rgb_flow.to(torch.float32).contiguous(),
+                                 mask.to(torch.float32).contiguous(), reps=1, cpad=eng.cin_pad)
+        return eng.stem(xin)
+
+    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None, x0=None):
+        """rows [rep*B + b]: sample b under class-keep mask keeps[rep] -> (len(keeps)*B, out_dim, H, W)."""
+        eng = self._engine
+        if x0 is None:
+            x0 = self._stem(x, rgb_flow, mask)
+        if len(keeps) > 1:
+            x0 = x0.repeat(len(keeps), 1, 1, 1)              # row copies of the shared stem output
         time = time.to(torch.int64).contiguous()
         classes = classes.to(torch.int64).contiguous()
-        xin = ops.assemble_input(x, rgb_flow, mask, reps=len(keeps), cpad=eng.cin_pad)
         cond = eng.embed(time, [(classes, k) for k in keeps], len(keeps))
-        return eng.trunk(xin, cond, taps)
+        return eng.trunk(x0, cond, taps)
 
     def forward(self, x, time, classes, rgb_flow, mask, cond_drop_prob=None):
         cond_drop_prob = default(cond_drop_prob, self.cond_drop_prob)
@@ -115,11 +122,12 @@ class Unet(nn.Module):
             if not hasattr(self, '_side'):
                 self._side = (torch.cuda.Stream(device=x.device), torch.cuda.Stream(device=x.device))
             cur = torch.cuda.current_stream()
+            x0 = self._stem(x, rgb_flow, mask)                # once, on the main stream
             outs = []
             for st, k in zip(self._side, (keep, null)):
                 st.wait_stream(cur)
                 with torch.cuda.stream(st):
-                    outs.append(self._run(x, time, classes, rgb_flow, mask, [k]))
+                    outs.append(self._run(x, time, classes, rgb_flow, mask, [k], x0=x0))
             for st, o in zip(self._side, outs):
                 cur.wait_stream(st)
                 o.record_stream(cur)

@@ -24,19 +24,27 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
   const int p0 = sp * LA_NS;
   const float* base = qkv + (size_t)b * n * 384;
 
-  float kr[LA_NS / 2];
-  float m = -INFINITY;
+  // the split's k AND v values are all requested up front (128 independent loads in flight per wave) and
+  // live in registers: the matrix loop below then never waits on memory
+  float kr[LA_NS / 2], vr[LA_NS / 2];
+  const float* kp = base + (size_t)p0 * 384 + 128 + h * 32 + d + (size_t)half * 384;
 #pragma unroll
   for (int i = 0; i < LA_NS / 2; ++i) {
     const int pix = p0 + 2 * i + half;
-    kr[i] = (pix < n) ? base[(size_t)pix * 384 + 128 + h * 32 + d] : -INFINITY;
-    m = fmaxf(m, kr[i]);
+    const bool ok = pix < n;
+    const float* q = ok ? kp + (size_t)i * 768 : kp;  // clamped address, masked value: no branch around a load
+    const float kv = q[0], vv = q[128];
+    kr[i] = ok ? kv : -INFINITY;
+    vr[i] = ok ? vv : 0.f;  // here d plays e
   }
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < LA_NS / 2; ++i) m = fmaxf(m, kr[i]);
   m = fmaxf(m, __shfl_xor(m, 32));
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LA_NS / 2; ++i) {
-    kr[i] = expf(kr[i] - m);
+    kr[i] = __expf(kr[i] - m);
     s += kr[i];
   }
   s += __shfl_xor(s, 32);
@@ -45,11 +53,7 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-  for (int i = 0; i < LA_NS / 2; ++i) {
-    const int pix = p0 + 2 * i + half;
-    const float vv = (pix < n) ? base[(size_t)pix * 384 + 256 + h * 32 + d] : 0.f;  // here d plays e
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[i], vv, acc, 0, 0, 0);
-  }
+  for (int i = 0; i < LA_NS / 2; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[i], vr[i], acc, 0, 0, 0);
   float* out = partial + ((size_t)(b * nsplit + sp) * 4 + h) * LA_PART;
   if (half == 0) {
     out[d] = m;

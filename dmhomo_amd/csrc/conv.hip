@@ -125,33 +125,33 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
   const int c4 = tid % C4;  // 256 % C4 == 0: a thread keeps its channel quad across its pixels
   int wbuf = 0;
 
-  // input (halo) tile of one channel chunk: global -> registers (issued one phase ahead of its use)
+  // input (halo) tile of one channel chunk: global -> registers (issued one phase ahead of its use).
+  // Pixel offsets and the validity mask do not depend on the chunk: computed once (every vector instruction
+  // in the chunk loop competes with the fp32 matrix pipe for the same ALUs).  Loads are UNCONDITIONAL from a
+  // clamped, always valid address and zeroed afterwards by the mask, so they stay in flight under counted waits.
   float4 v[NLOAD];
   float4 ca, cb;
-  unsigned inside;  // bit i: slot i holds image data (not zero padding)
+  int poff[NLOAD];
+  unsigned inside = 0;  // bit i: slot i holds image data (not zero padding)
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    const int pix = (tid + i * 256) / C4;
+    const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
+    const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
+    const bool ok = pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
+    const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
+    const int sy = UPS ? (yc >> 1) : yc, sx = UPS ? (xc >> 1) : xc;
+    poff[i] = (b * p.Hin + sy) * p.Win + sx;
+    inside |= (ok ? 1u : 0u) << i;
+  }
   auto issue_chunk_loads = [&](int ch) {
     const bool s1 = ch >= p.nch0;
     const float* src = s1 ? p.src1 : p.src0;
     const int Csrc = s1 ? p.C1 : p.C0;
     const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
-    const bool cvalid = c < Csrc;
-    // every slot loads UNCONDITIONALLY from a clamped (always valid) address and is zeroed afterwards by the
-    // `inside` mask: no branch around a load, so the loads stay in flight under counted vmcnt waits
-    inside = 0;
-    const int cc = cvalid ? c : 0;
+    const int cc = c < Csrc ? c : 0;
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const int f = tid + i * 256;
-      const int pix = f / C4;
-      const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
-      const int hy = pixc / IN_W, hx = pixc % IN_W;
-      const int yy = iy0 + hy, xx = ix0 + hx;
-      const bool ok = cvalid && pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
-      const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
-      const int sy = UPS ? (yc >> 1) : yc, sx = UPS ? (xc >> 1) : xc;
-      v[i] = ld4(src + ((size_t)(b * p.Hin + sy) * p.Win + sx) * Csrc + cc);
-      inside |= (ok ? 1u : 0u) << i;
-    }
+    for (int i = 0; i < NLOAD; ++i) v[i] = ld4(src + (size_t)poff[i] * Csrc + cc);
     ca = make_float4(1.f, 1.f, 1.f, 1.f);
     cb = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.in_coef != nullptr && !s1) {  // wave-uniform condition; clamped channel for the padded tail
@@ -160,18 +160,21 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
     }
   };
   issue_chunk_loads(0);
+  const int wr_in0 = (tid / C4) * KCP + c4 * 4;       // LDS offset of slot 0; slot i is 256 / C4 pixels further
+  const int wr_w0 = (tid / C4) * KCP + (tid % C4) * 4;  // weight-tile slot 0; slot i is 256 / C4 columns further
 
   for (int ch = 0; ch < nchunks; ++ch) {
-    const bool pro = (p.in_coef != nullptr) && ch < p.nch0;
+    const bool s1c = ch >= p.nch0;
+    const bool pro = (p.in_coef != nullptr) && !s1c;
+    const bool cvalid = (s1c ? ch - p.nch0 : ch) * KC + c4 * 4 < (s1c ? p.C1 : p.C0);
+    const unsigned msk = cvalid ? inside : 0u;
     __syncthreads();  // every wave is done reading in_tile of the previous chunk
     // ---- registers -> (prologue SiLU(a*x+b)) -> LDS
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      const int f = tid + i * 256;
-      const int pix = f / C4;
-      if (pix < IN_PIX) {
+      if ((i + 1) * 256 <= IN_PIX * C4 || (tid + i * 256) / C4 < IN_PIX) {
         float4 x = v[i];
-        if (!((inside >> i) & 1u)) {
+        if (!((msk >> i) & 1u)) {
           x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly zero: it pads the ACTIVATED tensor
         } else if (pro) {
           x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
           x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
           x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
         }
-        st4(in_tile + pix * KCP + c4 * 4, x);
+        st4(in_tile + wr_in0 + i * (256 / C4) * KCP, x);
       }
     }
 
@@ -187,10 +190,7 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
       // ---- publish the prefetched weight tile, prefetch the next one
       float* wt = w_tile + wbuf * Cfg::W_FLOATS;
 #pragma unroll
-      for (int i = 0; i < WL; ++i) {
-        const int f = tid + i * 256;
-        st4(wt + (f / C4) * KCP + (f % C4) * 4, wreg[i]);
-      }
+      for (int i = 0; i < WL; ++i) st4(wt + wr_w0 + i * (256 / C4) * KCP, wreg[i]);
       __syncthreads();
       {
         int nch = ch, ntap = tap + 1;
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
           for (int i = 0; i < WL; ++i) wreg[i] = ld4(wsrc + (size_t)(tid + i * 256) * 4);
         }
         // the next chunk's input tile travels during the last tap phase of this one
-        if (tap == NTAPS - 1 && ch + 1 < nchunks) issue_chunk_loads(ch + 1);
+        // (last chunk: a harmless re-load of itself — an unconditional issue lets hipcc count vmcnt exactly)
+        if (tap == NTAPS - 1) issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
       }
       // keep the prefetch loads ABOVE the matrix phase (hipcc otherwise sinks them next to their
       // consumer and the global latency lands on the critical path of every phase)

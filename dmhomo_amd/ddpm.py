@@ -58,7 +58,7 @@ class Unet(nn.Module):
         else:
             xin = ops.assemble_input(x, None, None, cpad=eng.cin_pad)
         cond = eng.embed(time, None, 1)
-        return eng.trunk(xin, cond)
+        return eng.trunk(eng.stem(xin), cond)
 
 
 class GaussianDiffusion(nn.Module, ScheduleHost):

@@ -209,8 +209,14 @@ class UnetEngine:
                 ops.linear(cm, self.c_w2, self.c_b2, out=cond[r * B:(r + 1) * B, td:])
         return cond
 
-    def trunk(self, xin, cond, taps=None):
-        """``taps`` (dict) optionally receives the NHWC activation after each stage member, keyed like the
+    def stem(self, xin):
+        """init_conv (CFG:432) on the assembled NHWC input; its output is shared by every CFG pass."""
+        self.ensure_prepared()
+        return ops.conv2d(self.init_conv, xin)
+
+    def trunk(self, x0, cond, taps=None):
+        """everything after init_conv.  x0: stem() output with one row per row of ``cond``.
+        ``taps`` (dict) optionally receives the NHWC activation after each stage member, keyed like the
         reference's module names ('downs.0.0', 'mid_attn', ...): per-layer parity tests."""
         self.ensure_prepared()
 
@@ -219,7 +225,7 @@ class UnetEngine:
                 taps[name] = v
             return v
         ss_all = ops.linear(cond, self.mlp_wt, self.mlp_b, act_in='silu')
-        x = tap('init_conv', ops.conv2d(self.init_conv, xin))
+        x = tap('init_conv', x0)
         r = x
         hs = []
         for i, (b1, b2, at, down) in enumerate(self.downs):
