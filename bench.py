@@ -15,9 +15,14 @@ independent), noise comes from the device Philox generator.  Samples shard acros
 data-path collective -> "scaling": "weak" (25 samples per GPU).
 
 Prints ONE JSON line on rank 0, including
-  roofline     the dominant kernel (3x3 implicit-GEMM conv on fp32 MFMA): algorithmic FLOPs of
-               its launches in the timed region / their HIP-event durations, vs the 157.3 TFLOP/s
-               dense fp32 matrix peak of MI355X (MI355X_MICROARCH.md)
+  roofline     the dominant kernel (3x3 conv, Winograd F(2x2,3x3) on fp32 MFMA): ALGORITHMIC FLOPs
+               (2*9*Cin*Cout*H*W*B) of its launches / their HIP-event durations, vs the
+               157.3 TFLOP/s dense fp32 matrix peak of MI355X (MI355X_MICROARCH.md).  Winograd executes
+               2.25x fewer matrix FLOPs than it is credited with, so `frac` can exceed the direct-conv
+               bound; `executed_frac` is the share of the matrix peak actually issued.  With
+               --cfg-mode streams (default) the two CFG passes run on two HIP streams and their kernels
+               overlap, so per-launch durations are not exclusive: the roofline leg is then measured on
+               one extra, untimed step in batched mode (same kernels, same shapes, 2B rows per launch)
   cpu_baseline the oracle (a port of the reference's CPU path, bit-equal to it on the build host)
                timed on this box's host cores on a bounded sample (bs=2, s_step=4, same network).
 """
@@ -87,7 +92,7 @@ def main():
     ap.add_argument('--image_size', type=int, default=128)
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cfg-mode', default='batched', choices=['batched', 'streams'])
+    ap.add_argument('--cfg-mode', default='streams', choices=['batched', 'streams'])
     ap.add_argument('--no-conv-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
 
@@ -135,6 +140,18 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     log, ops.CONV_LOG = ops.CONV_LOG, None
+    roofline_mode = args.cfg_mode
+    if log is not None and args.cfg_mode == 'streams':
+        # exclusive per-launch durations: one extra untimed step with the cond+null rows in ONE launch sequence
+        model.cfg_mode = 'batched'
+        step()
+        fence()
+        ops.CONV_LOG = []
+        step()
+        fence()
+        log, ops.CONV_LOG = ops.CONV_LOG, None
+        model.cfg_mode = args.cfg_mode
+        roofline_mode = 'batched (extra untimed step)'
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -164,12 +181,18 @@ def main():
                 if (cin, cout, ho) == (64, 64, args.image_size):
                     flc, msc, nc = flc + fl, msc + ms, nc + 1
             ach = fl3 / (ms3 * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+            if os.path.exists(tpath):       # FETCH_SIZE / WRITE_SIZE passes of rocprofv3 over this command
+                with open(tpath) as f:
+                    traffic = json.load(f)
             res['roofline'] = {
-                'kernel': 'conv_igemm_kernel<3,3,1,*> (3x3 conv, implicit GEMM on v_mfma_f32_32x32x2_f32)',
+                'kernel': 'conv_wino_kernel<*> (3x3 conv, Winograd F(2x2,3x3) on v_mfma_f32_16x16x4_f32)',
                 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                'frac': ach / PEAK_FP32_MFMA_TFLOPS,
+                'executed_TFLOP/s': ach / 2.25, 'executed_frac': ach / 2.25 / PEAK_FP32_MFMA_TFLOPS,
+                'traffic': traffic, 'measured_in': roofline_mode,
                 'launches': int(n3), 'avg_launch_us': ms3 / n3 * 1e3,
-                'time_share_of_step': ms3 * 1e-3 / elapsed,
                 'canonical_64to64_128sq': {'launches': int(nc), 'avg_launch_us': msc / max(nc, 1) * 1e3,
                                            'TFLOP/s': (flc / (msc * 1e-3) / 1e12) if msc else None,
                                            'GB/s_algorithmic': (nc * (4.0 * 2 * args.bs * args.image_size ** 2 * 128

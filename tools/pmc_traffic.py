@@ -1,0 +1,24 @@
+"""profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
+
+    python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <kernel substring> <out.json>
+Units / corrections as MI355X_MICROARCH.md §HBM prescribes: the counters are in KiB; on gfx950 FETCH_SIZE
+reports exactly half the bytes of a wide coalesced streaming read, so it is doubled; WRITE_SIZE is exact."""
+import csv, glob, json, sys
+
+
+def per_launch(d, counter, kernel):
+    f = glob.glob(d + '/**/*counter_collection.csv', recursive=True)[0]
+    vals = [float(r['Counter_Value']) for r in csv.DictReader(open(f))
+            if r['Counter_Name'] == counter and kernel in r['Kernel_Name']]
+    return sum(vals) / len(vals), len(vals)
+
+
+fetch_kib, n1 = per_launch(sys.argv[1], 'FETCH_SIZE', sys.argv[3])
+write_kib, n2 = per_launch(sys.argv[2], 'WRITE_SIZE', sys.argv[3])
+out = {'kernel': sys.argv[3], 'launches': n1,
+       'fetch_bytes_per_launch': 2 * fetch_kib * 1024, 'write_bytes_per_launch': write_kib * 1024,
+       'hbm_bytes_per_launch': 2 * fetch_kib * 1024 + write_kib * 1024,
+       'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 '
+               '--cfg-mode batched`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request)'}
+json.dump(out, open(sys.argv[4], 'w'), indent=1)
+print(out)
