@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cfg-mode', default='streams', choices=['batched', 'streams'])
+    ap.add_argument('--stream-splits', type=int, default=1, help="row sub-batches per CFG pass in 'streams' mode")
     ap.add_argument('--no-conv-events', action='store_true', help='skip the per-launch HIP events')
     args = ap.parse_args()
 
@@ -108,6 +109,7 @@ def main():
     torch.manual_seed(0)
     model = cfg.Unet(dim=args.dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
     model.cfg_mode = args.cfg_mode
+    model.stream_splits = args.stream_splits
     diffusion = cfg.GaussianDiffusion(model, image_size=args.image_size, timesteps=1000,
                                       sampling_timesteps=args.s_step, loss_type='l1', objective='pred_x0').to(device)
     D.broadcast_module_(diffusion, src=0)

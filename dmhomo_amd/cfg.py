@@ -112,6 +112,7 @@ class Unet(nn.Module):
     # sequences on two HIP streams, so one pass's HBM-bound kernels and kernel tails overlap the other's
     # matrix-bound kernels.  Results are identical (rows are independent, tests pin that bitwise).
     cfg_mode = 'batched'
+    stream_splits = 1      # 'streams' mode: row sub-batches per pass, each on its own stream
 
     def _cond_null(self, x, time, classes, rgb_flow, mask):
         """the two passes of CFG:404,409: (cond logits, null logits)."""
@@ -119,19 +120,28 @@ class Unet(nn.Module):
         keep = self._keep_mask(B, self.cond_drop_prob, x.device)
         null = torch.zeros((B,), device=x.device, dtype=torch.uint8)
         if self.cfg_mode == 'streams':
-            if not hasattr(self, '_side'):
-                self._side = (torch.cuda.Stream(device=x.device), torch.cuda.Stream(device=x.device))
+            nsub = max(1, min(int(self.stream_splits), B))       # row sub-batches per pass (each on its own stream)
+            nstreams = 2 * nsub
+            if len(getattr(self, '_side', ())) != nstreams:
+                self._side = tuple(torch.cuda.Stream(device=x.device) for _ in range(nstreams))
             cur = torch.cuda.current_stream()
             x0 = self._stem(x, rgb_flow, mask)                # once, on the main stream
-            outs = []
-            for st, k in zip(self._side, (keep, null)):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    outs.append(self._run(x, time, classes, rgb_flow, mask, [k], x0=x0))
-            for st, o in zip(self._side, outs):
+            cond_out = torch.empty((B, self.out_dim) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+            null_out = torch.empty_like(cond_out)
+            bounds = [(i * B) // nsub for i in range(nsub + 1)]
+            si = 0
+            for k, dst in ((keep, cond_out), (null, null_out)):
+                for lo, hi in zip(bounds[:-1], bounds[1:]):
+                    st = self._side[si]
+                    si += 1
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        kk = None if k is None else k[lo:hi].contiguous()
+                        o = self._run(None, time[lo:hi], classes[lo:hi], None, None, [kk], x0=x0[lo:hi])
+                        dst[lo:hi].copy_(o)
+            for st in self._side:
                 cur.wait_stream(st)
-                o.record_stream(cur)
-            return outs[0], outs[1]
+            return cond_out, null_out
         both = self._run(x, time, classes, rgb_flow, mask, [keep, null])
         return both[:B], both[B:]
 

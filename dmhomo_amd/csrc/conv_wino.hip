@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
                                 p.stats + ((size_t)(b * p.tilesX * p.tilesY + tile_in_sample) * p.Cout) * 2) + wave * 8;
     for (int i = 0; i < 6; ++i) d[i] = tk[i];
     d[6] = t_now - t_begin;
-    d[7] = t_begin;
+    d[7] = ((unsigned long long)__builtin_amdgcn_s_getreg((6) | (0 << 6) | (31 << 11)) << 32) |
+           __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));  // HW_REG_LDS_ALLOC : HW_REG_HW_ID
   }
 #else
   er.write_stats(p, lds, tile_in_sample);

@@ -25,5 +25,11 @@ tot = raw[..., 6].mean().item()
 print(f'shape {C0}->{Cout} @{H}x{W}, B={B}: mean wave lifetime {tot:.0f} cycles (memtime ticks)')
 for i in range(6):
     print(f'  {names[i]:12s} {raw[..., i].mean().item():9.0f}  {100 * raw[..., i].mean().item() / tot:5.1f} %')
-start = raw[..., 7]
-print('  start spread (first/last wave start, cycles):', (start.max() - start.min()).item())
+regs = st.view(torch.int64).reshape(B, tiles, -1)[:, :, :32].reshape(B, tiles, 4, 8)[..., 7].cpu().numpy().ravel()
+import collections
+lds_alloc = (regs >> 32) & 0xffffffff
+hw_id = regs & 0xffffffff
+print('  LDS_ALLOC values:', collections.Counter(int(v) for v in lds_alloc).most_common(6))
+print('  LDS_BASE  [7:0]  :', collections.Counter(int(v) & 0xff for v in lds_alloc).most_common(6))
+print('  HW_ID wave_id[3:0]:', collections.Counter(int(v) & 0xf for v in hw_id).most_common(8))
+print('  HW_ID tg_id[19:16]:', collections.Counter((int(v) >> 16) & 0xf for v in hw_id).most_common(8))
