@@ -62,6 +62,8 @@ SIGNATURES = {
     'dmh_affine': (c_int, [c_f32p, c_f32p, c_float, c_float, c_i64, C.c_void_p]),
     'dmh_affine_tail': (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_float, c_float, C.c_void_p]),
     'dmh_q_sample': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_i64, C.c_void_p]),
+    'dmh_diff_mean': (c_int, [c_f32p, c_f32p, c_f32p, c_int, C.c_void_p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_loss_combine': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, C.c_void_p]),
     'dmh_to_uint8': (c_int, [c_f32p, C.c_void_p, c_i64, C.c_void_p]),
     'dmh_homography_flow': (c_int, [C.c_void_p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, C.c_void_p]),
     'dmh_flow_to_image': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),

@@ -288,8 +288,50 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         cb = self.sqrt_one_minus_alphas_cumprod.gather(-1, t).contiguous()
         return ops.q_sample(x_start.contiguous(), noise.contiguous(), ca, cb)
 
+    @property
+    def loss_fn(self):
+        """CFG:744-751 — the name of the elementwise loss (the reduction runs in dmh_diff_mean)."""
+        if self.loss_type in ('l1', 'l2'):
+            return self.loss_type
+        raise ValueError(f'invalid loss type {self.loss_type}')
+
+    @torch.no_grad()
     def p_losses(self, x_start, t, *, classes, rgb_flow, flow, mask, noise=None):
-        raise NotImplementedError('training (p_losses + backward kernels) is SURVEY.md §8f "next" row 1, not built yet')
+        """CFG:770-806, FORWARD VALUE ONLY: q_sample -> UNet (class dropout p=0.5) -> flow_warp -> L1/L2 +
+        alpha_bar_t-weighted masked photometric term.  The returned scalar carries no autograd graph: backward
+        kernels / the training step are SURVEY.md §8f "next" row 1."""
+        from .ddpm import flow_warp
+        squared = self.loss_fn == 'l2'
+        noise = default(noise, lambda: self.rng.randn(x_start.shape, x_start.device))
+        x_start = x_start.to(torch.float32).contiguous()
+        noise = noise.to(torch.float32).contiguous()
+        t = t.to(torch.int64).contiguous()
+        x = self.q_sample(x_start, t, noise)
+        model_out = self.model(x, t, classes, rgb_flow=rgb_flow, mask=mask)
+        im1, im2 = model_out[:, :3].contiguous(), model_out[:, 3:].contiguous()
+        im2_warp = flow_warp(im2, flow)
+        if self.objective == 'pred_noise':
+            target = noise
+        elif self.objective == 'pred_x0':
+            target = x_start
+        elif self.objective == 'pred_v':                         # predict_v, CFG:596-598
+            ca = self.sqrt_alphas_cumprod.gather(-1, t).contiguous()
+            cb = (-self.sqrt_one_minus_alphas_cumprod).gather(-1, t).contiguous()
+            target = ops.q_sample(noise, x_start, ca, cb)
+        else:
+            raise ValueError(f'unknown objective {self.objective}')
+        loss = ops.diff_mean(model_out, target, None, squared)
+        photo = ops.diff_mean(im2_warp, im1, mask.to(torch.float32).contiguous(), squared)
+        w = self.alphas_cumprod.gather(-1, t).contiguous()
+        return ops.loss_combine(loss, photo, w)
 
     def forward(self, img, *args, **kwargs):
-        raise NotImplementedError('training (GaussianDiffusion.forward -> p_losses) is SURVEY.md §8f "next" row 1')
+        """CFG:808-842: split the 12-channel batch (DDP:1162 layout), draw t, evaluate p_losses (forward value)."""
+        b, c, h, w = img.shape
+        assert h == self.image_size and w == self.image_size, f'height and width of image must be {self.image_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
+        data = ops.affine(img[:, :6].to(torch.float32), 2., -1.)
+        mask = img[:, 6:7].contiguous()
+        rgb_flow = ops.affine(img[:, -5:-2].to(torch.float32), 2., -1.)
+        flow = img[:, -2:].contiguous()
+        return self.p_losses(data, t, *args, rgb_flow=rgb_flow, flow=flow, mask=mask, **kwargs)

@@ -138,6 +138,45 @@ __global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__
   }
 }
 
+// per-sample mean of m*|a-b| (or m*(a-b)^2): 64 blocks per sample accumulate in f64, fixed order
+__global__ __launch_bounds__(256) void diff_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ m, int squared,
+                                                           double* __restrict__ ws, int C, int HW) {
+  __shared__ double red[4];
+  const int s = blockIdx.y, blk = blockIdx.x;
+  const int64_t per = (int64_t)C * HW;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blk * 256 + threadIdx.x; i < per; i += 64 * 256) {
+    const float d = a[s * per + i] - b[s * per + i];
+    float v = squared ? d * d : fabsf(d);
+    if (m) v = m[(int64_t)s * HW + i % HW] * v;
+    acc += (double)v;
+  }
+  for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) ws[s * 64 + blk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void diff_final_kernel(const double* __restrict__ ws, float* __restrict__ out, int B, double inv_count) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= B) return;
+  double t = 0.0;
+  for (int i = 0; i < 64; ++i) t += ws[s * 64 + i];
+  out[s] = (float)(t * inv_count);
+}
+
+__global__ void loss_combine_kernel(const float* __restrict__ l, const float* __restrict__ ph,
+                                    const float* __restrict__ w, float* __restrict__ out, int B) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, p = 0.0;
+  for (int i = 0; i < B; ++i) {
+    a += (double)l[i];
+    p += (double)(1.0f * w[i] * ph[i]);
+  }
+  out[0] = (float)(a / B) + (float)(p / B);
+}
+
 static unsigned grid_for(int64_t n, int per_block = 256) {
   const int64_t g = cdiv64(n, per_block);
   return (unsigned)(g < 16384 ? (g > 0 ? g : 1) : 16384);
@@ -212,6 +251,24 @@ extern "C" int dmh_q_sample(const float* x_start, const float* noise, const floa
   hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_start, noise, ca, cb,
                      out, per_sample, total);
   DMH_CHECK_LAUNCH("dmh_q_sample");
+  return DMH_OK;
+}
+
+extern "C" int dmh_diff_mean(const float* a, const float* b, const float* m, int squared, double* ws, float* out, int B,
+                             int C, int HW, void* stream) {
+  DMH_REQUIRE(a && b && ws && out && B > 0 && C > 0 && HW > 0, "dmh_diff_mean: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(diff_partial_kernel, dim3(64, B), dim3(256), 0, st, a, b, m, squared, ws, C, HW);
+  DMH_CHECK_LAUNCH("dmh_diff_mean(partial)");
+  hipLaunchKernelGGL(diff_final_kernel, dim3(cdiv(B, 64)), dim3(64), 0, st, ws, out, B, 1.0 / ((double)C * HW));
+  DMH_CHECK_LAUNCH("dmh_diff_mean(final)");
+  return DMH_OK;
+}
+
+extern "C" int dmh_loss_combine(const float* l, const float* photo, const float* w, float* out, int B, void* stream) {
+  DMH_REQUIRE(l && photo && w && out && B > 0, "dmh_loss_combine: bad arguments");
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, l, photo, w, out, B);
+  DMH_CHECK_LAUNCH("dmh_loss_combine");
   return DMH_OK;
 }
 

@@ -221,6 +221,22 @@ def q_sample(x_start, noise, ca, cb):
     return out
 
 
+def diff_mean(a, b, mask=None, squared=False):
+    """per-sample mean over (C,H,W) of mask * |a-b| (or (a-b)^2): the loss terms of p_losses (CFG:796-802)."""
+    B, Cc, H, W = a.shape
+    ws = torch.empty((B, 64), device=a.device, dtype=torch.float64)
+    out = torch.empty((B,), device=a.device, dtype=F32)
+    call('dmh_diff_mean', ptr(a), ptr(b), ptr(mask), int(bool(squared)), ptr(ws, torch.float64), ptr(out), B, Cc,
+         H * W)
+    return out
+
+
+def loss_combine(l, photo, w):
+    out = torch.empty((1,), device=l.device, dtype=F32)
+    call('dmh_loss_combine', ptr(l), ptr(photo), ptr(w), ptr(out), l.shape[0])
+    return out[0]
+
+
 def to_uint8(img):
     out = torch.empty(img.shape, device=img.device, dtype=torch.uint8)
     call('dmh_to_uint8', ptr(img), ptr(out, torch.uint8), img.numel())

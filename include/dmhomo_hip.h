@@ -160,6 +160,13 @@ int dmh_affine_tail(float* x, int B, int C, int HW, int c0, float scale, float s
 /* D9 q_sample CFG:738-742: out = ca[b]*x_start + cb[b]*noise, ca/cb = extract(sqrt_ac / sqrt_1m_ac, t) */
 int dmh_q_sample(const float* x_start, const float* noise, const float* ca, const float* cb, float* out, int B,
                  int64_t per_sample, void* stream);
+/* D9 loss terms of p_losses (CFG:796-806), forward value only:
+ *   out[b] = mean over (C,HW) of m[b][hw] * |a - b|   (squared != 0: (a - b)^2); m may be NULL.
+ * Deterministic two-stage reduction; ws: [B][64] f64 scratch. */
+int dmh_diff_mean(const float* a, const float* b, const float* m, int squared, double* ws, float* out, int B, int C,
+                  int HW, void* stream);
+/* loss.mean() + (w * photo).mean() over the B per-sample means (CFG:804-806) -> out[0] */
+int dmh_loss_combine(const float* l, const float* photo, const float* w, float* out, int B, void* stream);
 /* G6  saveTrainPair DDP:1673: uint8 truncation of img*255 */
 int dmh_to_uint8(const float* img, uint8_t* out, int64_t n, void* stream);
 

@@ -289,3 +289,36 @@ def q_sample(buf, x_start, t, noise):
     nd = x_start.dim()
     return (extract(buf['sqrt_alphas_cumprod'], t, nd) * x_start +
             extract(buf['sqrt_one_minus_alphas_cumprod'], t, nd) * noise)
+
+
+def cfg_p_losses(sd, buf, x_start, t, classes, rgb_flow, flow, mask, noise, keep_mask, *, objective='pred_x0',
+                 loss_type='l1', groups=8):
+    """CFG GaussianDiffusion.p_losses, CFG:770-806 (forward value only).  ``keep_mask`` is the class-dropout
+    draw of the network call (CFG:780 -> CFG:415,422).  einops' ``reduce(x, 'b ... -> b (...)', 'mean')`` keeps
+    every axis (it only flattens), so both terms end in a plain mean over all elements."""
+    from . import geometry as G
+    import torch.nn.functional as F
+    x = q_sample(buf, x_start, t, noise)
+    out = U.cfg_unet_forward(sd, x, t, classes, rgb_flow, mask, keep_mask, groups)
+    im1, im2 = out[:, :3], out[:, 3:]
+    im2_warp = G.flow_warp(im2.contiguous(), flow)
+    if objective == 'pred_noise':
+        target = noise
+    elif objective == 'pred_x0':
+        target = x_start
+    elif objective == 'pred_v':
+        target = (extract(buf['sqrt_alphas_cumprod'], t, 4) * noise -
+                  extract(buf['sqrt_one_minus_alphas_cumprod'], t, 4) * x_start)           # CFG:596-598
+    else:
+        raise ValueError(f'unknown objective {objective}')
+    fn = {'l1': F.l1_loss, 'l2': F.mse_loss}[loss_type]
+    loss = fn(out, target, reduction='none').reshape(out.shape[0], -1)
+    photo = (mask * fn(im2_warp, im1, reduction='none')).reshape(out.shape[0], -1)
+    w = extract(buf['alphas_cumprod'], t, 2)
+    return loss.mean() + (1 * w * photo).mean()
+
+
+def cfg_forward_split(img):
+    """CFG GaussianDiffusion.forward's slicing of the 12-channel batch, CFG:814-840 (DDP:1162 layout)."""
+    data, mask, rgb_flow, flow = img[:, :6], img[:, 6:7], img[:, -5:-2], img[:, -2:]
+    return data * 2 - 1, mask, rgb_flow * 2 - 1, flow

@@ -255,6 +255,27 @@ def main():
     arrays.update({'rgb_flow01': rgb01, 'mask': mask, 'flow': flow, 'classes': classes})
     npz('ddim_trace', **arrays)
 
+    # ---------------------------------------------------------------- F8 train_step forward value (CFG p_losses)
+    arrays = {}
+    g8 = torch.Generator().manual_seed(61)
+    img12 = torch.rand(2, 12, 16, 16, generator=g8)
+    img12[:, 6:7] = (img12[:, 6:7] > 0.4).float()
+    img12[:, -2:] = (img12[:, -2:] - 0.5) * 6
+    tt = torch.tensor([17, 803])
+    nz = torch.randn(2, 6, 16, 16, generator=g8)
+    arrays.update({'img12': img12, 't': tt, 'noise': nz, 'classes': classes})
+    for obj, lt in (('pred_x0', 'l1'), ('pred_noise', 'l2'), ('pred_v', 'l1')):
+        d = cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=4, objective=obj, loss_type=lt)
+        data, mk, rf, fl = img12[:, :6] * 2 - 1, img12[:, 6:7], img12[:, -5:-2] * 2 - 1, img12[:, -2:]
+        torch.manual_seed(7)
+        keep = torch.zeros(2).float().uniform_(0, 1) < 0.5
+        torch.manual_seed(7)
+        with torch.no_grad():
+            loss = d.p_losses(data, tt, classes=classes, rgb_flow=rf, flow=fl, mask=mk, noise=nz)
+        arrays[f'{obj}.{lt}.loss'] = loss
+        arrays[f'{obj}.{lt}.keep'] = keep
+    npz('train_forward', **arrays)
+
     # ---------------------------------------------------------------- F6 ddpm_trace (DDP)
     arrays = {}
     for sc in (False, True):

@@ -233,3 +233,53 @@ def test_state_dict_roundtrip_through_trainer(tmp_path):
     tr2.load(7)
     for (k, a), (_, b) in zip(d.state_dict().items(), d2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize('obj,lt', [('pred_x0', 'l1'), ('pred_noise', 'l2'), ('pred_v', 'l1')])
+def test_p_losses_forward_vs_golden(golden_dir, obj, lt):
+    """F8: the reference's own p_losses value (CFG:770-806), forward only"""
+    from dmhomo_amd import cfg
+    gd = load(golden_dir, 'train_forward')
+    m, sd = make_cfg(8)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=4, objective=obj,
+                              loss_type=lt).to(dev())
+    img12 = T(gd['img12'])
+    data, mk, rf, fl = img12[:, :6] * 2 - 1, img12[:, 6:7], img12[:, -5:-2] * 2 - 1, img12[:, -2:]
+    m.rng = ReplayDeviceRng([torch.where(T(gd[f'{obj}.{lt}.keep']), 0.25, 0.75)])
+    loss = d.p_losses(g(data), g(T(gd['t'])), classes=g(T(gd['classes'])), rgb_flow=g(rf.contiguous()),
+                      flow=g(fl.contiguous()), mask=g(mk.contiguous()), noise=g(T(gd['noise'])))
+    want = float(gd[f'{obj}.{lt}.loss'])
+    print(f'[parity] p_losses {obj}/{lt}: got {float(loss):.7f} want {want:.7f}')
+    assert abs(float(loss) - want) <= 2e-4 * max(1.0, abs(want))
+    # GaussianDiffusion.forward: 12-channel split + random t (device RNG) -> finite scalar
+    m.rng = cfg.DeviceRng()
+    val = d(g(img12), classes=g(T(gd['classes'])))
+    assert val.ndim == 0 and bool(torch.isfinite(val))
+
+
+def test_unet_stress_geometry_vs_oracle():
+    """BASELINE config 5 geometry: dim=128, 256x256 (1024-key bottleneck attention, 65536-pixel linear attention)"""
+    from dmhomo_amd import cfg
+    m = cfg.Unet(dim=128, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    sd = det_state_dict(shapes_of(m), 3)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    x, rf, mk = _cond_inputs(1, 256, 500)
+    t, c = torch.tensor([499]), torch.zeros(1, dtype=torch.long)
+    rtaps, taps = {}, {}
+    with torch.no_grad():
+        ref = OU.cfg_unet_forward(sd, x, t, c, rf, mk, None, taps=rtaps)
+    out = m._run(g(x), g(t), g(c), g(rf), g(mk), [None], taps=taps)
+    worst = max(report('stress ' + k, nchw(taps[k]), rtaps[k])[1] for k in ('downs.0.2', 'mid_attn', 'ups.3.3'))
+    assert worst < 1e-3, worst
+    close('stress out', out.cpu(), ref, rtol=1e-3, atol=3e-4)
+
+
+def test_unet_ddp_fullsize_vs_oracle():
+    """unconditional UNet (pixel-unshuffle Downsample, self-conditioning) at dim=64, 128x128"""
+    m, sd = make_ddp(64, True)
+    x, xs = rand((2, 3, 128, 128), 600), rand((2, 3, 128, 128), 601)
+    t = torch.tensor([12, 907])
+    with torch.no_grad():
+        ref = OU.ddp_unet_forward(sd, x, t, xs, True)
+    close('ddp full', m(g(x), g(t), g(xs)).cpu(), ref, rtol=1e-3, atol=2e-4)

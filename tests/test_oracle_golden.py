@@ -175,6 +175,19 @@ def test_ddim_trace_seeded_stream(golden_dir, meta):
         assert torch.equal(d, T(g[f'pred_x0.draw{i}'])), i
 
 
+# ------------------------------------------------------------------------- F8
+@pytest.mark.parametrize('obj,lt', [('pred_x0', 'l1'), ('pred_noise', 'l2'), ('pred_v', 'l1')])
+def test_train_forward(golden_dir, meta, obj, lt):
+    g = load(golden_dir, 'train_forward')
+    sd = sd_from(meta, 'unet_cfg_tiny')
+    buf = OD.schedule_buffers(1000, 'cosine')
+    data, mk, rf, fl = OD.cfg_forward_split(T(g['img12']))
+    with torch.no_grad():
+        loss = OD.cfg_p_losses(sd, buf, data, T(g['t']), T(g['classes']), rf, fl, mk, T(g['noise']),
+                               T(g[f'{obj}.{lt}.keep']), objective=obj, loss_type=lt)
+    close(loss, g[f'{obj}.{lt}.loss'], rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------- F6
 @pytest.mark.parametrize('tag', ['nosc', 'sc'])
 def test_ddpm_trace(golden_dir, meta, tag):
