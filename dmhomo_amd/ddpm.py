@@ -335,7 +335,7 @@ class Trainer(object):
     def sample(self, idx, rank, step=1):
         """DDP:1941-2021 without the every-100-steps PNG/GIF dumps (visualisation is out of scope)."""
         data = next(self.dl)
-        dev = torch.device('cuda', rank) if isinstance(rank, int) else rank
+        dev = torch.device('cuda', rank) if isinstance(rank, int) else torch.device(rank)
         rgb_flows = data[0][:, -5:-2].to(dev)
         flows = data[0][:, -2:].to(dev).contiguous()
         mask = data[0][:, -6:-5].to(dev)

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Drop-in counterpart of the reference's DGM/dgm_sample.py on dmhomo_amd (same CLI flags, same output format).
+
+    python scripts/dgm_sample.py -c DGM --s_step 32 --bs 25 --exp run0 [--image_size 256] [--batches 2]
+
+Differences from the reference script (DGM/dgm_sample.py:11-101), all forced by what is available offline:
+  * conditions come from dmhomo_amd.ddpm.SyntheticConditions (the CA-Homo dataset of DDP:1058-1066 is not
+    shipped) unless --conditions points at a .pt file holding an iterable of (12-channel batch, classes);
+  * -c names results/model-<c>.pt like the reference; when the file does not exist the seeded random
+    initialisation is used (the trained DGM.pt lives on HuggingFace, README:8);
+  * the loop stops after --batches batches instead of running until killed (SAMPLE:62);
+  * multi-GPU: launch with torch.distributed.run instead of N hand-started processes (--gpu_nums / -i are
+    still accepted and select the data slice exactly as the reference's unused arguments did: not at all).
+Output: traindata/<exp>/dataset/idx_<i>_rank_<r>_part_<p>_dm_cahomo_<k>k.npy — a pickled list of
+{"imgs": uint8 (B,6,H,W), "homos": float64 (B,3,3)} every 2 batches (SAMPLE:73-77), the format
+HEM/dataset/data_loader.py:123-131 consumes.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dmhomo_amd.denoising_diffusion_models.denoising_diffusion_pytorch import Trainer  # noqa: E402
+from dmhomo_amd.denoising_diffusion_models.classifier_free_guidance import Unet, GaussianDiffusion  # noqa: E402
+from dmhomo_amd import distributed as D  # noqa: E402
+
+parser = argparse.ArgumentParser()
+parser.add_argument('-c', type=str, default='None')
+parser.add_argument('--gpu_nums', type=int, default=0)
+parser.add_argument('--s_step', type=int, default=0)
+parser.add_argument('--part', type=int, default=0)
+parser.add_argument('--bs', type=int, default=80)
+parser.add_argument('--exp', type=str, default='exp')
+parser.add_argument('-i', type=int, default=0)
+parser.add_argument('--image_size', type=int, default=256)        # SAMPLE:32 hard-codes 256
+parser.add_argument('--batches', type=int, default=2)
+parser.add_argument('--conditions', type=str, default=None)
+args = parser.parse_args()
+
+num_classes = 1
+
+
+def main():
+    rank, world, device = D.init_from_env()
+    model = Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=6, num_classes=num_classes).to(device)
+    model.cfg_mode = 'streams'
+    diffusion = GaussianDiffusion(model, image_size=args.image_size, timesteps=1000, sampling_timesteps=args.s_step,
+                                  loss_type='l1', objective='pred_x0').to(device)
+    folder = torch.load(args.conditions) if args.conditions else 'DGM_Conditions'
+    trainer = Trainer(diffusion, folder, train_batch_size=args.bs, train_lr=1e-4, train_num_steps=200000,
+                      gradient_accumulate_every=2, ema_decay=0.995, amp=False, results_folder='results',
+                      save_and_sample_every=2000, num_samples=4, augment_horizontal_flip=False, num_worker=0,
+                      total_data_slice_idx=args.gpu_nums, data_slice_idx=args.i, shuffle=False)
+    if os.path.exists(os.path.join('results', f'model-{args.c}.pt')):
+        trainer.load(args.c)
+    else:
+        print(f'results/model-{args.c}.pt not found: sampling from the seeded random initialisation')
+    D.broadcast_module_(diffusion, src=0)
+    out_dir = f'traindata/{args.exp}/dataset/'
+    os.makedirs(out_dir, exist_ok=True)
+    train_list, part = [], args.part
+    for _ in range(args.batches):
+        ret = trainer.sample(args.i, device, step=len(train_list))
+        train_list.append(ret)
+        print(f'length of trainList {len(train_list)}')
+        if len(train_list) % 2 == 0:
+            np.save(f'{out_dir}idx_{args.i}_rank_{rank}_part_{part}_dm_cahomo_{len(train_list) * args.bs / 1000}k.npy',
+                    np.array(train_list, dtype=object), allow_pickle=True)
+            train_list.clear()
+            part += 1
+
+
+if __name__ == '__main__':
+    main()
