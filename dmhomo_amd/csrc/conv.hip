@@ -308,13 +308,15 @@ static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
 // 3x3 tiling variants (development knob DMH_CONV3_VARIANT, read once; the default is the measured best):
 //   0..3  conv_igemm_kernel   (KC,TH) = (32,16) (16,16) (32,8) (16,8)
 //   6     conv_wino_kernel    Winograd F(2x2,3x3), 8x16 pixels x 64 cout per workgroup
+//   7     conv_bf16x3_kernel  direct implicit GEMM on the bf16 matrix cores, fp32 carried as 3 bf16 pieces
+//   8     conv_wino_bf16x3_kernel  Winograd F(2x2,3x3) on the bf16 matrix cores, fp32 carried as 3 bf16 pieces
 #define DMH_CONV3_DEFAULT 6
 static int conv3_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DMH_CONV3_VARIANT");
     v = e ? atoi(e) : DMH_CONV3_DEFAULT;
-    if (v < 0 || v > 6 || v == 4 || v == 5) v = DMH_CONV3_DEFAULT;
+    if (v < 0 || v > 8 || v == 4 || v == 5) v = DMH_CONV3_DEFAULT;
   }
   return v;
 }
@@ -342,6 +344,8 @@ extern "C" int dmh_conv_tiles(int Hout, int Wout, int KH, int stride) {
 
 extern "C" int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW) {
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack_floats(Cout, C0, C1);
+  if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack_floats(Cout, C0, C1, KH, KW);
+  if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack_floats(Cout, C0, C1);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 64 * KC;
@@ -353,6 +357,8 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   DMH_REQUIRE(KH == KW && (KH == 1 || KH == 2 || KH == 3 || KH == 4 || KH == 7),
               "dmh_pack_conv_weight: unsupported kernel %dx%d", KH, KW);
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
+  if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
+  if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
@@ -391,6 +397,8 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 2: return launch_conv<3, 3, 1, 0, 32, 8, 16, 3>(d, Hout, Wout, st);
         case 3: return launch_conv<3, 3, 1, 0, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
+        case 7: return dmh_bf16x3_launch3(d, Hout, Wout, st);
+        case 8: return dmh_winobx_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 0, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
     case 311:
@@ -399,6 +407,8 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 2: return launch_conv<3, 3, 1, 1, 32, 8, 16, 3>(d, Hout, Wout, st);
         case 3: return launch_conv<3, 3, 1, 1, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
+        case 7: return dmh_bf16x3_launch3(d, Hout, Wout, st);
+        case 8: return dmh_winobx_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
     case 710: return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);

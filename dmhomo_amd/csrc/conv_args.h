@@ -16,6 +16,7 @@ struct ConvArgs {
   float* stats;
   int B, Hin, Win, C0, C1, Cout, Hout, Wout;
   int nch0, nch1, tilesX, tilesY;
+  int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
 };
 
 
@@ -42,6 +43,7 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
   a.nch1 = cdiv(a.C1, KC);
   a.tilesX = cdiv(Wout, TW);
   a.tilesY = cdiv(Hout, TH);
+  a.ablate = 0;
   return a;
 }
 
@@ -50,6 +52,16 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
 int64_t dmh_wino_pack_floats(int Cout, int C0, int C1);
 int dmh_wino_pack(const float* w, float* wpack, int Cout, int C0, int C1, hipStream_t st);
 int dmh_wino_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
+
+// bf16x3 split path (conv_bf16x3.hip)
+int64_t dmh_bf16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW);
+int dmh_bf16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st);
+int dmh_bf16x3_launch3(const DmhConv* d, int Hout, int Wout, hipStream_t st);
+
+// Winograd on the bf16 matrix cores, fp32 carried as three bf16 pieces (conv_wino_bf16x3.hip)
+int64_t dmh_winobx_pack_floats(int Cout, int C0, int C1);
+int dmh_winobx_pack(const float* w, float* wpack, int Cout, int C0, int C1, hipStream_t st);
+int dmh_winobx_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 
 // Second half of every conv epilogue: an LDS slab holds rows = output pixels x 64 channels (pitch EP);
 // each wave turns 32 slab rows into NHWC float4 stores: + bias, + residual (optionally through
@@ -82,13 +94,20 @@ struct EpilogueRows {
   // wl: this wave's 32 slab rows; row_base: tile-row index of slab row 0 (row -> pixel (row / TW, row % TW))
   template <int TW>
   __device__ __forceinline__ void store_rows(const ConvArgs& p, const float* wl, int row_base, int oy0, int ox0) {
+    const int c4_ = c4;
+    store_rows_fn<TW>(p, [wl, c4_](int rr) { return ld4(wl + rr * EP + c4_ * 4); }, row_base, oy0, ox0);
+  }
+
+  // same, the 32 rows x this lane's channel quad coming from fetch(rr) instead of a plain slab
+  template <int TW, typename Fetch>
+  __device__ __forceinline__ void store_rows_fn(const ConvArgs& p, Fetch fetch, int row_base, int oy0, int ox0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rr = i * 4 + rsub;
       const int row = row_base + rr;
       const int oy = oy0 + row / TW, ox = ox0 + row % TW;
       if (cok && oy < p.Hout && ox < p.Wout) {
-        float4 val = ld4(wl + rr * EP + c4 * 4);
+        float4 val = fetch(rr);
         const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;
         val.x += bias.x;
         val.y += bias.y;
@@ -121,10 +140,61 @@ struct EpilogueRows {
     }
   }
 
-  // cross-lane + cross-wave (4 waves, through LDS) reduction of the partials -> stats[b][tile][Cout][2]
+  // Variant for the WM x WN wave grids of conv_bf16x3.hip (each wave: 64 pixels x its own 64-channel block).
+  // Stat tiles are 8 rows x 16 columns (= two waves along M) whatever the workgroup tile, so the tile count
+  // does not depend on Cout: stats[b][stat tile][Cout][2] with stat tile = (ty * TH/8 + g) * tilesX + tx.
+  template <int WM, int WN, int TH>
+  __device__ __forceinline__ void write_stats_grid(const ConvArgs& p, float* lds, int ty, int tx) {
+    if (!p.stats) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      s1.x += __shfl_xor(s1.x, off);
+      s1.y += __shfl_xor(s1.y, off);
+      s1.z += __shfl_xor(s1.z, off);
+      s1.w += __shfl_xor(s1.w, off);
+      s2.x += __shfl_xor(s2.x, off);
+      s2.y += __shfl_xor(s2.y, off);
+      s2.z += __shfl_xor(s2.z, off);
+      s2.w += __shfl_xor(s2.w, off);
+    }
+    __syncthreads();
+    float* red = lds;
+    if (lane < 16) {
+      float* q = red + (wave * 64 + c4 * 4) * 2;
+      q[0] = s1.x;
+      q[1] = s2.x;
+      q[2] = s1.y;
+      q[3] = s2.y;
+      q[4] = s1.z;
+      q[5] = s2.z;
+      q[6] = s1.w;
+      q[7] = s2.w;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int q = tid >> 6, c = tid & 63;
+      const int g = WN == 1 ? q : 0, wnq = WN == 1 ? 0 : q;
+      const int chan = (blockIdx.y * WN + wnq) * 64 + c;
+      const int srow = ty * (TH / 8) + g;
+      if (chan < p.Cout && srow * 8 < p.Hout) {
+        const int w0 = (g * 2 + 0) * WN + wnq, w1 = (g * 2 + 1) * WN + wnq;
+        const float a0 = red[(w0 * 64 + c) * 2 + 0] + red[(w1 * 64 + c) * 2 + 0];
+        const float a1 = red[(w0 * 64 + c) * 2 + 1] + red[(w1 * 64 + c) * 2 + 1];
+        const int stiles = ((p.Hout + 7) / 8) * p.tilesX;
+        float* st = p.stats + ((size_t)(b * stiles + srow * p.tilesX + tx) * p.Cout + chan) * 2;
+        st[0] = a0;
+        st[1] = a1;
+      }
+    }
+  }
+
+  // cross-lane + cross-wave reduction of the partials -> stats[b][tile][Cout][2].  Every group of 4 waves
+  // (256 threads) owns one 64-channel block (n0 already points at it) and reduces through its own LDS patch.
   __device__ __forceinline__ void write_stats(const ConvArgs& p, float* lds, int tile_in_sample) {
     if (!p.stats) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, tid = threadIdx.x & 255;
+    lds += (threadIdx.x >> 8) * 512;
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {
       s1.x += __shfl_xor(s1.x, off);

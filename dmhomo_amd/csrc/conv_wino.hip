@@ -25,7 +25,6 @@ constexpr int RAW_FLOATS = IN_PIX * RAWP;          // 3600
 constexpr int V_FLOATS = 16 * 4 * NT * 4;          // 8192: [pos][kq][tile][4]
 constexpr int SLAB_FLOATS = 128 * EpilogueRows::EP;  // epilogue slab: 128 pixels x 68
 constexpr int LDS_FLOATS = (RAW_FLOATS + V_FLOATS) > SLAB_FLOATS ? (RAW_FLOATS + V_FLOATS) : SLAB_FLOATS;
-constexpr int NLOAD = (IN_PIX * 4 + 255) / 256;    // 3 float4 per thread per chunk
 constexpr int PD = 4;                              // weight prefetch depth in positions
 }  // namespace
 
@@ -49,8 +48,14 @@ __device__ __forceinline__ f4 operator-(const f4& a, const f4& b) { return f4{a.
 // instruction in the chunk loop is paid in matrix throughput.  Everything chunk-invariant (halo pixel
 // offsets, validity mask, LDS offsets of the transform items) is therefore computed once, global loads use
 // a uniform (scalar) base + a precomputed 32-bit lane offset, and the transforms use packed fp32 adds.
-template <int UPS>
-__global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
+// G = 1: 4 waves, 64 output channels per workgroup, two workgroups per CU.
+// G = 2: 8 waves, 128 output channels per workgroup (one per CU): the staging + input transform of a chunk
+//        is shared by twice the matrix work, for layers with Cout % 128 == 0.
+template <int UPS, int G>
+__global__ __launch_bounds__(256 * G, 2) void conv_wino_kernel(ConvArgs p) {
+  constexpr int NTHR = 256 * G;
+  constexpr int NLOAD = (IN_PIX * 4 + NTHR - 1) / NTHR;  // halo float4 slots per thread per chunk
+  constexpr int NIT = 512 / NTHR;                        // transform items per thread per chunk
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* raw = lds;
   float* V = lds + RAW_FLOATS;
@@ -58,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;  // 2 (tiles) x 2 (cout) waves
+  const int gq = wave >> 2;                              // which 64-channel block of this workgroup
+  const int wm = (wave >> 1) & 1, wn = wave & 1;         // 2 (tiles) x 2 (cout) waves per block
   const int j16 = lane & 15, kq = lane >> 4;
 
   int t = blockIdx.x;
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
   t /= p.tilesX;
   const int ty0 = t % p.tilesY;
   const int b = t / p.tilesY;
-  const int nt = blockIdx.y;
+  const int nt = blockIdx.y * G + gq;
   const int n0 = nt * 64;
   const int tile_in_sample = ty0 * p.tilesX + tx0;
   const int oy0 = ty0 * TH, ox0 = tx0 * TW;
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
     const int Wlim = UPS ? p.Win * 2 : p.Win;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      const int pix = (tid + i * 256) >> 2;
+      const int pix = (tid + i * NTHR) >> 2;
       const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
       const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
       const bool ok = pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
@@ -108,11 +114,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
     }
   }
   // LDS offsets of this thread's two transform items (tile, channel quad cq, row xi): chunk-invariant too
-  int rd_a[2], rd_b[2], wr_v[2];
-  float sgn[2];
+  int rd_a[NIT], rd_b[NIT], wr_v[NIT];
+  float sgn[NIT];
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int item = tid + it * 256;
+  for (int it = 0; it < NIT; ++it) {
+    const int item = tid + it * NTHR;
     const int tile = item & 31, cq = (item >> 5) & 3, xi = item >> 7;
     const int ty = tile >> 3, tx = tile & 7;
     // rows of d that enter row xi of B^T d:  xi0: d0-d2, xi1: d1+d2, xi2: d2-d1, xi3: d1-d3
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
     rd_b[it] = ((2 * ty + rb_) * IN_W + 2 * tx) * RAWP + cq * 4;
     wr_v[it] = (((xi * 4) * 4 + cq) * NT + tile) * 4;  // position 4*xi + nu, k-quarter cq
   }
-  const int wr_raw0 = (tid >> 2) * RAWP + c4 * 4;  // slot i lives 64 pixels further: + i * 64 * RAWP
+  const int wr_raw0 = (tid >> 2) * RAWP + c4 * 4;  // slot i lives NTHR/4 pixels further
 
   floatx4 acc[16][2];
 #pragma unroll
@@ -161,6 +167,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
 
   for (int ch = 0; ch < nchunks; ++ch) {
     // ---- 1. registers -> (prologue SiLU(a*x+b)) -> raw LDS tile
+#ifdef DMH_STAMPS
+    if (!(p.ablate & 1))
+#endif
     {
       const bool s1 = ch >= p.nch0;
       const bool pro = (p.in_coef != nullptr) && !s1;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
       const unsigned m = cvalid ? inside : 0u;
 #pragma unroll
       for (int i = 0; i < NLOAD; ++i) {
-        if (i < NLOAD - 1 || ((tid + i * 256) >> 2) < IN_PIX) {
+        if (i < NLOAD - 1 || ((tid + i * NTHR) >> 2) < IN_PIX) {
           float4 x = v[i];
           if (!((m >> i) & 1u)) {
             x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly zero: it pads the ACTIVATED tensor
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
             x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
             x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
           }
-          st4(raw + wr_raw0 + i * (64 * RAWP), x);
+          st4(raw + wr_raw0 + i * ((NTHR / 4) * RAWP), x);
         }
       }
     }
@@ -199,8 +208,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
     issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
 
     // ---- 2. input transform V = B^T d B, two items per thread, packed fp32 adds
+#ifdef DMH_STAMPS
+    if (!(p.ablate & 1))
+#endif
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const float* pa = raw + rd_a[it];
       const float* pb = raw + rd_b[it];
       const float2v sg = float2v{sgn[it], sgn[it]};
@@ -222,6 +234,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
     STAMP(3)          // barrier 2
 
     // ---- 3. matrix phase: M_pos[tile][cout] += V_pos[tile][k] * U_pos[k][cout], 16 positions
+#ifdef DMH_STAMPS
+    if (!(p.ablate & 2))
+#endif
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const float4 a = ld4(va + q * (4 * NT * 4));
@@ -246,6 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
   // ---- output transform Y = A^T M A, register-local: lane holds M_pos[tile = wm*16 + kq*4 + r][cout = .. + j16]
   __syncthreads();  // all waves left the last matrix phase: LDS becomes the pixel x channel slab
   constexpr int EP = EpilogueRows::EP;
+  float* slab = lds + gq * SLAB_FLOATS;  // one 128-pixel x 64-channel slab per 4-wave group
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int col = (wn * 2 + nb) * 16 + j16;
@@ -260,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
         tt[0][nu] = m0 + m1 + m2;
         tt[1][nu] = m1 - m2 - m3;
       }
-      float* sl = lds + ((2 * ty) * TW + 2 * tx) * EP + col;
+      float* sl = slab + ((2 * ty) * TW + 2 * tx) * EP + col;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         sl[(i * TW) * EP] = tt[i][0] + tt[i][1] + tt[i][2];
@@ -270,10 +286,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(ConvArgs p) {
   }
   __syncthreads();
   EpilogueRows er(p, b, n0);
-  er.template store_rows<TW>(p, lds + wave * (32 * EP), wave * 32, oy0, ox0);
+  er.template store_rows<TW>(p, slab + (wave & 3) * (32 * EP), (wave & 3) * 32, oy0, ox0);
 #ifdef DMH_STAMPS
   STAMP(5)  // output transform + row epilogue
-  if (p.stats && lane == 0 && nt == 0) {
+  if (p.stats && lane == 0 && nt == 0 && G == 1) {
     unsigned long long* d = reinterpret_cast<unsigned long long*>(
                                 p.stats + ((size_t)(b * p.tilesX * p.tilesY + tile_in_sample) * p.Cout) * 2) + wave * 8;
     for (int i = 0; i < 6; ++i) d[i] = tk[i];
@@ -346,11 +362,38 @@ int dmh_wino_pack(const float* w, float* wpack, int Cout, int C0, int C1, hipStr
 
 int dmh_wino_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   ConvArgs a = fill_conv_args(d, Hout, Wout, KC, TH, TW);
+#ifdef DMH_STAMPS
+  {
+    const char* e = getenv("DMH_WINO_ABLATE");
+    a.ablate = e ? atoi(e) : 0;
+  }
+#endif
+  static int wide = -1;  // development knob: DMH_WINO_WIDE=0 disables the 128-channel workgroups
+  if (wide < 0) {
+    const char* e = getenv("DMH_WINO_WIDE");
+    wide = e ? atoi(e) : 1;
+  }
+  if (wide && a.Cout % 128 == 0) {
+    constexpr int LDSW = (2 * SLAB_FLOATS > LDS_FLOATS ? 2 * SLAB_FLOATS : LDS_FLOATS) * 4;  // 69.6 KB
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv_wino_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
+      (void)hipFuncSetAttribute((const void*)conv_wino_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSW);
+      attr = true;
+    }
+    dim3 grid(a.tilesX * a.tilesY * a.B, a.Cout / 128);
+    if (d->upsample2)
+      hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(512), LDSW, st, a);
+    else
+      hipLaunchKernelGGL((conv_wino_kernel<0, 2>), grid, dim3(512), LDSW, st, a);
+    DMH_CHECK_LAUNCH("dmh_conv2d(winograd, 128-channel workgroups)");
+    return DMH_OK;
+  }
   dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
   if (d->upsample2)
-    hipLaunchKernelGGL((conv_wino_kernel<1>), grid, dim3(256), LDS_FLOATS * 4, st, a);
+    hipLaunchKernelGGL((conv_wino_kernel<1, 1>), grid, dim3(256), LDS_FLOATS * 4, st, a);
   else
-    hipLaunchKernelGGL((conv_wino_kernel<0>), grid, dim3(256), LDS_FLOATS * 4, st, a);
+    hipLaunchKernelGGL((conv_wino_kernel<0, 1>), grid, dim3(256), LDS_FLOATS * 4, st, a);
   DMH_CHECK_LAUNCH("dmh_conv2d(winograd)");
   return DMH_OK;
 }
