@@ -310,16 +310,20 @@ static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
 //   6     conv_wino_kernel    Winograd F(2x2,3x3), 8x16 pixels x 64 cout per workgroup
 //   7     conv_bf16x3_kernel  direct implicit GEMM on the bf16 matrix cores, fp32 carried as 3 bf16 pieces
 //   8     conv_wino_bf16x3_kernel  Winograd F(2x2,3x3) on the bf16 matrix cores, fp32 carried as 3 bf16 pieces
-#define DMH_CONV3_DEFAULT 6
+//   9     conv_f16x3_kernel   direct implicit GEMM on the fp16 matrix cores, block-scaled 2 x 3 fp16 pieces
+#define DMH_CONV3_DEFAULT 9
 static int conv3_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DMH_CONV3_VARIANT");
     v = e ? atoi(e) : DMH_CONV3_DEFAULT;
-    if (v < 0 || v > 8 || v == 4 || v == 5) v = DMH_CONV3_DEFAULT;
+    if (v < 0 || v > 9 || v == 4 || v == 5) v = DMH_CONV3_DEFAULT;
   }
   return v;
 }
+
+// the fp16-piece kernel serves 3x3 and 1x1 stride-1 convolutions when variant 9 (the default) is selected
+static bool use_f16x3(int KH, int stride) { return conv3_variant() == 9 && stride == 1 && (KH == 3 || KH == 1); }
 
 static int conv_out_dim(int in, int KH, int stride, int ups) {
   if (ups) return in * 2;
@@ -329,6 +333,7 @@ static int conv_out_dim(int in, int KH, int stride, int ups) {
 
 static int conv_th(int KH, int stride) {
   if (stride == 2) return 8;
+  if (use_f16x3(KH, stride)) return 8;  // GroupNorm partials per 8 x 16 stat tile
   if (KH == 3 && (conv3_variant() == 2 || conv3_variant() == 3 || conv3_variant() >= 5)) return 8;
   return 16;
 }
@@ -346,6 +351,7 @@ extern "C" int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack_floats(Cout, C0, C1);
   if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack_floats(Cout, C0, C1, KH, KW);
   if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack_floats(Cout, C0, C1);
+  if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1)) return dmh_f16x3_pack_floats(Cout, C0, C1, KH, KW);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 64 * KC;
@@ -359,6 +365,7 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
   if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
   if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
+  if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1)) return dmh_f16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
@@ -390,7 +397,9 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
   const int key = d->KH * 100 + d->stride * 10 + d->upsample2;
   DMH_REQUIRE(d->KH == d->KW, "dmh_conv2d: non-square kernel");
   switch (key) {
-    case 110: return launch_conv<1, 1, 1, 0, 32, 16, 16>(d, Hout, Wout, st);
+    case 110:
+      if (use_f16x3(1, 1)) return dmh_f16x3_launch(d, Hout, Wout, st);
+      return launch_conv<1, 1, 1, 0, 32, 16, 16>(d, Hout, Wout, st);
     case 310:
       switch (conv3_variant()) {
         case 1: return launch_conv<3, 3, 1, 0, 16, 16, 16, 3>(d, Hout, Wout, st);
@@ -399,6 +408,7 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
         case 7: return dmh_bf16x3_launch3(d, Hout, Wout, st);
         case 8: return dmh_winobx_launch(d, Hout, Wout, st);
+        case 9: return dmh_f16x3_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 0, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
     case 311:
@@ -409,6 +419,7 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
         case 7: return dmh_bf16x3_launch3(d, Hout, Wout, st);
         case 8: return dmh_winobx_launch(d, Hout, Wout, st);
+        case 9: return dmh_f16x3_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
     case 710: return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);

@@ -14,6 +14,7 @@ struct ConvArgs {
   const float* res_coef;
   float* out;
   float* stats;
+  const float* oscale;  // per-output-channel power-of-two factor undoing the weight scaling (conv_f16x3.hip), or null
   int B, Hin, Win, C0, C1, Cout, Hout, Wout;
   int nch0, nch1, tilesX, tilesY;
   int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
@@ -31,6 +32,7 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
   a.res_coef = d->res_coef;
   a.out = d->out;
   a.stats = d->stats;
+  a.oscale = nullptr;
   a.B = d->B;
   a.Hin = d->Hin;
   a.Win = d->Win;
@@ -58,6 +60,11 @@ int64_t dmh_bf16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW);
 int dmh_bf16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st);
 int dmh_bf16x3_launch3(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 
+// fp16 split path: two activation pieces x three weight planes, block-scaled (conv_f16x3.hip)
+int64_t dmh_f16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW);
+int dmh_f16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st);
+int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
+
 // Winograd on the bf16 matrix cores, fp32 carried as three bf16 pieces (conv_wino_bf16x3.hip)
 int64_t dmh_winobx_pack_floats(int Cout, int C0, int C1);
 int dmh_winobx_pack(const float* w, float* wpack, int Cout, int C0, int C1, hipStream_t st);
@@ -71,7 +78,7 @@ struct EpilogueRows {
   static constexpr int EP = 68;  // slab pitch in floats (64 + 4)
   int b, n0, chn, c4, rsub;
   bool cok;
-  float4 bias, ra, rb, s1, s2;
+  float4 bias, ra, rb, s1, s2, osc;
 
   __device__ __forceinline__ EpilogueRows(const ConvArgs& p, int b_, int n0_) : b(b_), n0(n0_) {
     const int lane = threadIdx.x & 63;
@@ -84,6 +91,8 @@ struct EpilogueRows {
     rb = bias;
     s1 = bias;
     s2 = bias;
+    osc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (cok && p.oscale) osc = ld4(p.oscale + chn);
     if (cok && p.bias) bias = ld4(p.bias + chn);
     if (cok && p.res_coef) {
       ra = ld4(p.res_coef + (size_t)(b * 2 + 0) * p.Cout + chn);
@@ -109,10 +118,10 @@ struct EpilogueRows {
       if (cok && oy < p.Hout && ox < p.Wout) {
         float4 val = fetch(rr);
         const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;
-        val.x += bias.x;
-        val.y += bias.y;
-        val.z += bias.z;
-        val.w += bias.w;
+        val.x = fmaf(val.x, osc.x, bias.x);  // osc == 1 unless the kernel scaled its weights: then exactly val + bias
+        val.y = fmaf(val.y, osc.y, bias.y);
+        val.z = fmaf(val.z, osc.z, bias.z);
+        val.w = fmaf(val.w, osc.w, bias.w);
         if (p.res) {
           const float4 rv = ld4(p.res + o);
           if (p.res_coef) {

@@ -227,9 +227,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(ConvArgs p) {
 #define DMH_TERM(sa, sb)                                                                                   \
   acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mb][sa], __builtin_bit_cast(bf16x8, bq[k16][nb * 3 + sb]), \
                                                         acc[mb][nb], 0, 0, 0);
-            DMH_TERM(2, 0)
-            DMH_TERM(0, 2)
-            DMH_TERM(1, 1)
+            if (!(ABL & 4)) {
+              DMH_TERM(2, 0)
+              DMH_TERM(0, 2)
+              DMH_TERM(1, 1)
+            }
             DMH_TERM(1, 0)
             DMH_TERM(0, 1)
             DMH_TERM(0, 0)
@@ -356,6 +358,8 @@ int dmh_bf16x3_launch3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
       case 1: return wide ? launch_split<3, 3, 1, 0, 8, 16, 2, 2, 1>(d, Hout, Wout, st) : launch_split<3, 3, 1, 0, 16, 16, 4, 1, 1>(d, Hout, Wout, st);
       case 2: return wide ? launch_split<3, 3, 1, 0, 8, 16, 2, 2, 2>(d, Hout, Wout, st) : launch_split<3, 3, 1, 0, 16, 16, 4, 1, 2>(d, Hout, Wout, st);
       case 3: return wide ? launch_split<3, 3, 1, 0, 8, 16, 2, 2, 3>(d, Hout, Wout, st) : launch_split<3, 3, 1, 0, 16, 16, 4, 1, 3>(d, Hout, Wout, st);
+      case 4: return wide ? launch_split<3, 3, 1, 0, 8, 16, 2, 2, 4>(d, Hout, Wout, st) : launch_split<3, 3, 1, 0, 16, 16, 4, 1, 4>(d, Hout, Wout, st);
+      case 7: return wide ? launch_split<3, 3, 1, 0, 8, 16, 2, 2, 7>(d, Hout, Wout, st) : launch_split<3, 3, 1, 0, 16, 16, 4, 1, 7>(d, Hout, Wout, st);
     }
   }
 #endif

@@ -1,0 +1,391 @@
+// K1 / K2 on the fp16 matrix cores — convolution as an implicit GEMM whose fp32 operands are carried as fp16
+// pieces under block scaling ("f16x3": three MFMAs per fp32 product block, fp32 accumulation).
+//
+// Why: on gfx950 the fp32 MFMA executes on the vector ALUs at the fp32 VALU rate (157 TFLOP/s, no overlap with
+// any other vector work: tools/micro/coexec.hip).  The 16-bit MFMAs run on the matrix cores proper at 16x that
+// rate, so three of them per product block are ~5x cheaper than one fp32 MFMA.
+//
+// Arithmetic (all scalings are powers of two, hence exact):
+//   activations  xs = x * s            s per (workgroup, running over chunks): the largest |x| staged so far sits in
+//                                       [2^14, 2^15); when a later chunk raises the maximum the accumulators are rescaled
+//                h1 = fp16(xs)                       11 significant bits
+//                h2 = fp16((xs - h1) * 2^11)         the next 11 bits; the subtraction is exact, the scaled residual
+//                                                    has the magnitude of h1, so it never falls into fp16 subnormals
+//   weights      ws = w * 2^k          k per output channel: max |w| of the channel sits in [2^14, 2^15)   (pack time)
+//                g1 = fp16(ws),  g2 = fp16(ws - g1),  g1s = fp16(g1 * 2^-11)
+//   product      x*w*s*2^k = h1*g1 + h1*g2 + h2*g1s + (h2*g2*2^-11 + rounding of the pieces) : the dropped part is
+//                <= 2^-22 relative, every fp16*fp16 product is exact in fp32, the MFMA accumulates in fp32
+//   output       y = acc / s * 2^-k + bias
+// 22-24 significant bits per operand relative to the block maximum, fp32 exponent range, no overflow by
+// construction.  Against an fp64 convolution the error is that of the fp32-MFMA kernels (fp32 accumulation
+// rounding dominates both): tests/test_gpu_kernels.py.
+//
+//   M = output pixels: each wave owns 64 (two 32-row blocks);  N = 64 output channels per wave (two 32 blocks)
+//   workgroup = 4 waves as WM x WN:  4x1 -> 16x16 pixels x 64 cout,   2x2 -> 8x16 pixels x 128 cout
+//   K = taps x input channels in chunks of 32 channels: per chunk the (halo) input tile is staged ONCE into LDS —
+//       through the fused prologue SiLU(a*x+b) when a GroupNorm is pending — as two fp16 planes and reused by
+//       all taps; the weight planes stream from L2 in fragment order, one coalesced 1 KB load per wave each,
+//       prefetched one K step ahead.
+// Epilogue: shared with conv.hip (LDS transpose, + bias, + residual, float4 NHWC stores, GroupNorm partials).
+//
+// Replaces: the 3x3 convolutions of Block / ResnetBlock CFG:128-170, the Upsample conv CFG:106-107 and the
+// 1x1 convolutions (to_qkv / to_out / res_conv) of CFG:176-245.
+#include <stdlib.h>
+
+#include "common.h"
+
+#include "conv_args.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 32;                // input channels per chunk
+constexpr int PITCH = 144;            // LDS bytes per staged pixel: 2 planes x 32 fp16 + 16 (odd multiple of 16 B)
+constexpr int STEP_U4 = 6 * 64;       // uint4 per (chunk, tap, k16): 2 column blocks x 3 planes x 64 lanes
+
+template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
+struct F16Cfg {
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  static_assert(TH * TW == WM * 64, "64 pixels per wave");
+  static constexpr int IN_H = (TH - 1) * S + KH;
+  static constexpr int IN_W = (TW - 1) * S + KW;
+  static constexpr int IN_PIX = IN_H * IN_W;
+  static constexpr int NLOAD = (IN_PIX * 8 + 255) / 256;
+  static constexpr int PAD = (S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0);
+  static constexpr int IN_BYTES = IN_PIX * PITCH;
+  static constexpr int EPI_BYTES = 4 * 32 * EpilogueRows::EP * 4;
+  static constexpr int TILE_BYTES = IN_BYTES > EPI_BYTES ? IN_BYTES : EPI_BYTES;
+  static constexpr int LDS_BYTES = TILE_BYTES + 16;  // + the two block-maximum slots
+};
+
+__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+
+}  // namespace
+
+template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
+  using Cfg = F16Cfg<KH, KW, S, UPS, TH, TW, WM, WN>;
+  constexpr int IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, NLOAD = Cfg::NLOAD, NTAPS = KH * KW;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned char* in_tile = reinterpret_cast<unsigned char*>(lds);
+  unsigned* mxslot = reinterpret_cast<unsigned*>(in_tile + Cfg::TILE_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  int t = blockIdx.x;
+  const int tx = t % p.tilesX;
+  t /= p.tilesX;
+  const int ty = t % p.tilesY;
+  const int b = t / p.tilesY;
+  const int nt = blockIdx.y * WN + wn;
+  const int n0 = nt * 64;
+
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int iy0 = oy0 * S - Cfg::PAD, ix0 = ox0 * S - Cfg::PAD;
+  const int Hlim = UPS ? p.Hin * 2 : p.Hin;
+  const int Wlim = UPS ? p.Win * 2 : p.Win;
+
+  if (tid < 2) mxslot[tid] = 0u;
+
+  // LDS byte offset of this lane's A rows at tap (0,0), plane 0, k16 step 0
+  int arow[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int r = wm * 64 + mb * 32 + l31;
+    const int py = r / TW, px = r % TW;
+    arow[mb] = ((py * S) * IN_W + px * S) * PITCH + half * 16;
+  }
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+  const int nchunks = p.nch0 + p.nch1;
+  const int nsteps = nchunks * NTAPS * 2;
+  const uint4* wbase = reinterpret_cast<const uint4*>(p.wpack) + (size_t)nt * nsteps * STEP_U4 + lane;
+
+  // B fragments of one K step: [column block][plane g1, g2, g1s]; double buffered across steps
+  uint4 bq[2][6];
+  auto load_b = [&](int buf, int step) {
+    const uint4* src = wbase + (size_t)(step < nsteps ? step : nsteps - 1) * STEP_U4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) bq[buf][i] = src[i * 64];
+  };
+  load_b(0, 0);
+
+  // input (halo) tile of one channel chunk: global -> registers, issued one chunk ahead.  Unconditional loads
+  // from clamped addresses + a validity mask (see conv.hip) keep them in flight under counted waits.
+  const int c4 = tid & 7;
+  float4 v[NLOAD];
+  float4 ca, cb;
+  int poff[NLOAD];
+  unsigned inside = 0;
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    const int pix = (tid + i * 256) >> 3;
+    const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
+    const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
+    const bool ok = pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
+    const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
+    const int sy = UPS ? (yc >> 1) : yc, sx = UPS ? (xc >> 1) : xc;
+    poff[i] = (b * p.Hin + sy) * p.Win + sx;
+    inside |= (ok ? 1u : 0u) << i;
+  }
+  auto issue_chunk_loads = [&](int ch) {
+    const bool s1 = ch >= p.nch0;
+    const float* src = s1 ? p.src1 : p.src0;
+    const int Csrc = s1 ? p.C1 : p.C0;
+    const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
+    const int cc = c < Csrc ? c : 0;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) v[i] = ld4(src + (size_t)poff[i] * Csrc + cc);
+    ca = make_float4(1.f, 1.f, 1.f, 1.f);
+    cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.in_coef != nullptr && !s1) {
+      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + cc);
+      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + cc);
+    }
+  };
+  issue_chunk_loads(0);
+  const int wr0 = (tid >> 3) * PITCH + c4 * 8;  // staging slot 0; slot i is 32 pixels further
+  __syncthreads();                              // block-maximum slots are zeroed
+
+  int e_run = 16;  // biased exponent of the running block maximum (clamped to [16, 254]); uniform
+  int step = 0;
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const bool s1c = ch >= p.nch0;
+    const bool pro = (p.in_coef != nullptr) && !s1c;
+    const bool cvalid = (s1c ? ch - p.nch0 : ch) * KC + c4 * 4 < (s1c ? p.C1 : p.C0);
+    const unsigned msk = cvalid ? inside : 0u;
+    // ---- values of this chunk (prologue applied, padding zeroed) stay in v[]; their largest magnitude -> LDS slot
+    unsigned mx = 0u;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      float4 x = v[i];
+      if (!((msk >> i) & 1u)) {
+        x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding is exactly zero: it pads the ACTIVATED tensor
+      } else if (pro) {
+        x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
+        x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
+        x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
+        x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
+      }
+      v[i] = x;
+      mx = max(max(mx, absbits(x.x)), max(max(absbits(x.y), absbits(x.z)), absbits(x.w)));
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if (lane == 0) atomicMax(&mxslot[ch & 1], mx);
+    __syncthreads();  // block maximum complete; every wave is done reading the previous chunk's tile
+    const unsigned bmx = mxslot[ch & 1];
+    if (tid == 0) mxslot[(ch + 1) & 1] = 0u;
+    // ---- block scale: running maximum over the chunks, so the scale only ever shrinks (no overflow on rescale)
+    const int e_old = e_run;
+    const int e_ch = min(max((int)(__builtin_amdgcn_readfirstlane(bmx) >> 23), 16), 254);
+    e_run = max(e_run, e_ch);
+    const float sc = __uint_as_float((unsigned)(268 - e_run) << 23);  // largest |x| * sc in [2^14, 2^15)
+    if (e_run != e_old && ch > 0) {
+      const int fe = 127 + e_old - e_run;
+      const float f = fe > 0 ? __uint_as_float((unsigned)fe << 23) : 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mb][nb][r] *= f;
+    }
+    // ---- split into two fp16 planes -> LDS
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      if ((i + 1) * 256 <= IN_PIX * 8 || ((tid + i * 256) >> 3) < IN_PIX) {
+        const float4v xs = float4v{v[i].x, v[i].y, v[i].z, v[i].w} * sc;
+        const half4 h1 = __builtin_convertvector(xs, half4);
+        const float4v rs = (xs - __builtin_convertvector(h1, float4v)) * 2048.f;
+        const half4 h2 = __builtin_convertvector(rs, half4);
+        unsigned char* dst = in_tile + wr0 + i * 32 * PITCH;
+        *reinterpret_cast<half4*>(dst) = h1;
+        *reinterpret_cast<half4*>(dst + 64) = h2;
+      }
+    }
+    __syncthreads();
+    // the next chunk's tile travels during this chunk's matrix phase (last chunk: harmless re-load of itself)
+    issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int kh = tap / KW, kw = tap % KW;
+      const unsigned char* at = in_tile + (kh * IN_W + kw) * PITCH;
+#pragma unroll
+      for (int k16 = 0; k16 < 2; ++k16) {
+        load_b(k16 ^ 1, step + 1);  // prefetch the next K step's weights (other buffer)
+        __builtin_amdgcn_sched_barrier(0);
+        half8 a[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) a[mb][s] = *reinterpret_cast<const half8*>(at + arow[mb] + s * 64 + k16 * 32);
+#define DMH_TERM(sa, sb)                                                                                             \
+  _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc[mb][nb] =  \
+      __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][sa], __builtin_bit_cast(half8, bq[k16][nb * 3 + sb]), acc[mb][nb], 0, \
+                                             0, 0);
+        DMH_TERM(1, 2)  // h2 * g1s   (smallest terms first)
+        DMH_TERM(0, 1)  // h1 * g2
+        DMH_TERM(0, 0)  // h1 * g1
+#undef DMH_TERM
+        ++step;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // ---- epilogue: accumulators / block scale -> LDS transpose -> rows (conv_args.h applies 2^-k per channel)
+  {
+    constexpr int EP = EpilogueRows::EP;
+    const float inv_s = __uint_as_float((unsigned)(e_run - 14) << 23);  // 1 / sc
+    float* wl = lds + wave * (32 * EP);
+    EpilogueRows er(p, b, n0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      __syncthreads();
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          wl[((r & 3) + 8 * (r >> 2) + 4 * half) * EP + nb * 32 + l31] = acc[mb][nb][r] * inv_s;
+      __syncthreads();
+      er.template store_rows<TW>(p, wl, wm * 64 + mb * 32, oy0, ox0);
+    }
+    er.template write_stats_grid<WM, WN, TH>(p, lds, ty, tx);
+  }
+}
+
+// ------------------------------------------------------------------------------ weight packing
+// per-output-channel scale: 2^k with max |w| * 2^k in [2^14, 2^15); oscale[c] = 2^-k (1 for padded / all-zero channels)
+__global__ __launch_bounds__(64) void f16x3_wscale_kernel(const float* __restrict__ w, float* __restrict__ oscale,
+                                                           int Cout, int K) {
+  const int o = blockIdx.x;
+  float m = 0.f;
+  if (o < Cout)
+    for (int i = threadIdx.x; i < K; i += 64) m = fmaxf(m, fabsf(w[(size_t)o * K + i]));
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);  // m = f * 2^e, f in [0.5, 1)  ->  m * 2^(15 - e) in [2^14, 2^15)
+      s = ldexpf(1.f, min(max(e - 15, -100), 100));
+    }
+    oscale[o] = s;
+  }
+}
+
+// fp16 element index: ((((((nt * nchunks + ch) * NTAPS + tap) * 2 + k16) * 2 + nb) * 3 + plane) * 64 + lane) * 8 + j
+//   -> plane (g1, g2, g1s) of w[o = nt*64 + nb*32 + (lane & 31)][c = chunk channel k16*16 + (lane >> 5)*8 + j][tap] * 2^k
+__global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const float* __restrict__ oscale,
+                                         _Float16* __restrict__ wp, int Cout, int C0, int C1, int NTAPS, int nch0,
+                                         int nch1, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int64_t r = idx;
+  const int j = r % 8;
+  r /= 8;
+  const int lane = r % 64;
+  r /= 64;
+  const int plane = r % 3;
+  r /= 3;
+  const int nb = r % 2;
+  r /= 2;
+  const int k16 = r % 2;
+  r /= 2;
+  const int tap = r % NTAPS;
+  r /= NTAPS;
+  const int ch = r % (nch0 + nch1);
+  const int nt = r / (nch0 + nch1);
+  const int o = nt * 64 + nb * 32 + (lane & 31);
+  const int k = k16 * 16 + (lane >> 5) * 8 + j;
+  int c;
+  bool ok;
+  if (ch < nch0) {
+    c = ch * KC + k;
+    ok = c < C0;
+  } else {
+    c = (ch - nch0) * KC + k;
+    ok = c < C1;
+    c += C0;
+  }
+  float ws = 0.f;
+  if (ok && o < Cout) ws = w[((size_t)o * (C0 + C1) + c) * NTAPS + tap] / oscale[o];  // exact: a power of two
+  const _Float16 g1 = (_Float16)ws;
+  const _Float16 g2 = (_Float16)(ws - (float)g1);
+  const _Float16 g1s = (_Float16)((float)g1 * (1.f / 2048.f));
+  wp[idx] = plane == 0 ? g1 : (plane == 1 ? g2 : g1s);
+}
+
+static int64_t f16x3_frag_floats(int Cout, int C0, int C1, int KH, int KW) {
+  return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 2 * STEP_U4 * 4;
+}
+
+int64_t dmh_f16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW) {
+  return f16x3_frag_floats(Cout, C0, C1, KH, KW) + (int64_t)cdiv(Cout, 64) * 64;  // + the per-channel 2^-k
+}
+
+int dmh_f16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st) {
+  const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
+  const int64_t frag = f16x3_frag_floats(Cout, C0, C1, KH, KW);
+  float* oscale = wpack + frag;
+  hipLaunchKernelGGL(f16x3_wscale_kernel, dim3(cdiv(Cout, 64) * 64), dim3(64), 0, st, w, oscale, Cout,
+                     (C0 + C1) * KH * KW);
+  const int64_t total = frag * 2;  // fp16 elements
+  hipLaunchKernelGGL(pack_f16x3_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, w, oscale,
+                     reinterpret_cast<_Float16*>(wpack), Cout, C0, C1, KH * KW, nch0, nch1, total);
+  DMH_CHECK_LAUNCH("dmh_pack_conv_weight(f16x3)");
+  return DMH_OK;
+}
+
+template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
+static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
+  using Cfg = F16Cfg<KH, KW, S, UPS, TH, TW, WM, WN>;
+  ConvArgs a = fill_conv_args(d, Hout, Wout, KC, TH, TW);
+  a.oscale = d->wpack + f16x3_frag_floats(d->Cout, a.C0, a.C1, KH, KW);
+  auto kern = conv_f16x3_kernel<KH, KW, S, UPS, TH, TW, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       Cfg::LDS_BYTES);
+    DMH_REQUIRE(e == hipSuccess, "dmh_conv2d: cannot raise the LDS limit: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64 * WN));
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, a);
+  DMH_CHECK_LAUNCH("dmh_conv2d(f16x3)");
+  return DMH_OK;
+}
+
+// 3x3 / 1x1 stride 1 (3x3 optionally behind a nearest x2 upsample).  Cout a multiple of 128: 8x16 pixels x 128
+// channels per workgroup (half the staging per flop); otherwise 16x16 pixels x 64 channels.
+int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
+  const bool wide = d->Cout % 128 == 0;
+  if (d->KH == 1) {
+    return wide ? launch_f16x3<1, 1, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st)
+                : launch_f16x3<1, 1, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);
+  }
+  if (d->upsample2) {
+    return wide ? launch_f16x3<3, 3, 1, 1, 8, 16, 2, 2>(d, Hout, Wout, st)
+                : launch_f16x3<3, 3, 1, 1, 16, 16, 4, 1>(d, Hout, Wout, st);
+  }
+  return wide ? launch_f16x3<3, 3, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st)
+              : launch_f16x3<3, 3, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);
+}

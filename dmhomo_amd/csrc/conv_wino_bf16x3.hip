@@ -12,10 +12,11 @@
 //
 // Per workgroup: 8x16 output pixels (32 Winograd tiles) x 64 output channels; per 16-channel chunk
 //   1. the 10x18 input halo is staged to LDS (fp32) through the fused GroupNorm+SiLU prologue,
-//   2. all 256 threads transform it, V = B^T d B, split V into bf16 pieces and store
-//      V[16 positions][3 pieces][32 tiles][16 k] — each (position, piece) is one contiguous 1 KB A fragment,
+//   2. all 256 threads transform it, V = B^T d B -> V[16 positions][k quarter][32 tiles][4] (fp32, double buffered),
 //   3. wave w multiplies the four positions of Winograd row w: M_pos[32 tiles][64 cout] on
-//      v_mfma_f32_32x32x16_bf16, the pre-transformed, pre-split weights U streaming from L2 in fragment order.
+//      v_mfma_f32_32x32x16_bf16; it splits its A fragment into bf16 pieces at the load, the pre-transformed,
+//      pre-split weights U stream from L2 in fragment order.
+// The three steps of consecutive chunks are software pipelined (see the kernel).
 // Output transform: wave w contracts its row over nu in registers, the rows are exchanged through LDS and
 // contracted over xi while the shared float4 row epilogue (+bias, +residual, GroupNorm partials) reads them.
 //
@@ -29,13 +30,14 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 namespace {
 constexpr int TH = 8, TW = 16, KC = 16, IN_H = 10, IN_W = 18, IN_PIX = IN_H * IN_W, NT = 32;
-constexpr int RAWP = 24;                         // raw tile pitch in floats (96 B: conflict-free transform reads)
-constexpr int RAW_BYTES = IN_PIX * RAWP * 4;     // 17280
-constexpr int V_BYTES = 16 * 3 * NT * 32;        // 49152: [pos][piece][tile][16 bf16]
+constexpr int RAWP = 20;                         // raw tile pitch in floats
+constexpr int RAW_FLOATS = IN_PIX * RAWP;        // 3600
+constexpr int V_FLOATS = 16 * 4 * NT * 4;        // 8192 per buffer: [pos][k quarter][tile][4] fp32
 constexpr int ZP = 68;                           // exchange pitch in floats
-constexpr int Z_BYTES = 4 * 2 * NT * ZP * 4;     // 69632: [row xi][j][tile][cout]
-constexpr int MAIN_BYTES = RAW_BYTES + V_BYTES;
-constexpr int LDS_BYTES = MAIN_BYTES > Z_BYTES ? MAIN_BYTES : Z_BYTES;
+constexpr int Z_FLOATS = 4 * 2 * NT * ZP;        // 17408: [row xi][j][tile][cout]
+constexpr int MAIN_FLOATS = RAW_FLOATS + 2 * V_FLOATS;
+constexpr int LDS_FLOATS = MAIN_FLOATS > Z_FLOATS ? MAIN_FLOATS : Z_FLOATS;  // 79936 B: two workgroups per CU
+constexpr int LDS_BYTES = LDS_FLOATS * 4;
 constexpr int NLOAD = (IN_PIX * 4 + 255) / 256;  // halo float4 slots per thread per chunk
 constexpr int POS_U4 = 6 * 64;                   // uint4 per position of packed U: 2 column blocks x 3 pieces x 64 lanes
 
@@ -46,6 +48,7 @@ __device__ __forceinline__ f4 ldf4(const float* p) {
   const float4 t = ld4(p);
   return f4{float2v{t.x, t.y}, float2v{t.z, t.w}};
 }
+__device__ __forceinline__ void stf4(float* p, const f4& v) { st4(p, make_float4(v.lo.x, v.lo.y, v.hi.x, v.hi.y)); }
 __device__ __forceinline__ f4 operator+(const f4& a, const f4& b) { return f4{a.lo + b.lo, a.hi + b.hi}; }
 __device__ __forceinline__ f4 operator-(const f4& a, const f4& b) { return f4{a.lo - b.lo, a.hi - b.hi}; }
 
@@ -54,22 +57,45 @@ __device__ __forceinline__ unsigned pack_hi16(float a, float b) {  // top halves
 }
 __device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
 
-// four floats -> three bf16 pieces each (8 B per piece); both subtractions are exact
-__device__ __forceinline__ void split_store(unsigned char* dst, const f4& x) {
-  const float x0 = x.lo.x, x1 = x.lo.y, x2 = x.hi.x, x3 = x.hi.y;
-  const float r0 = x0 - trunc_bf16(x0), r1 = x1 - trunc_bf16(x1), r2 = x2 - trunc_bf16(x2), r3 = x3 - trunc_bf16(x3);
-  const float s0 = r0 - trunc_bf16(r0), s1 = r1 - trunc_bf16(r1), s2 = r2 - trunc_bf16(r2), s3 = r3 - trunc_bf16(r3);
-  *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(x0, x1), pack_hi16(x2, x3));
-  *reinterpret_cast<uint2*>(dst + NT * 32) = make_uint2(pack_hi16(r0, r1), pack_hi16(r2, r3));
-  *reinterpret_cast<uint2*>(dst + 2 * NT * 32) = make_uint2(pack_hi16(s0, s1), pack_hi16(s2, s3));
+// eight floats (one lane's K slice of an A fragment) -> three bf16x8 pieces; both subtractions are exact
+__device__ __forceinline__ void split8(const float4& f0, const float4& f1, bf16x8 (&a)[3]) {
+  const float x[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+  float r[8], s[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    r[i] = x[i] - trunc_bf16(x[i]);
+    s[i] = r[i] - trunc_bf16(r[i]);
+  }
+  a[0] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(x[0], x[1]), pack_hi16(x[2], x[3]), pack_hi16(x[4], x[5]),
+                                               pack_hi16(x[6], x[7])));
+  a[1] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3]), pack_hi16(r[4], r[5]),
+                                               pack_hi16(r[6], r[7])));
+  a[2] = __builtin_bit_cast(bf16x8, make_uint4(pack_hi16(s[0], s[1]), pack_hi16(s[2], s[3]), pack_hi16(s[4], s[5]),
+                                               pack_hi16(s[6], s[7])));
 }
+
+struct True_ {
+  static constexpr bool value = true;
+};
+struct False_ {
+  static constexpr bool value = false;
+};
 }  // namespace
 
-template <int UPS>
+// Software pipeline, one stage per chunk c, two barriers per stage, everything between two barriers in ONE
+// instruction stream so that the bf16 MFMAs (asynchronous once issued) run beside the vector work:
+//   half 1:  matrix(c) positions 0,1   +  input transform of chunk c+1: raw -> V[(c+1) & 1]
+//   half 2:  matrix(c) positions 2,3   +  raw tile of chunk c+2 (registers -> prologue -> LDS), loads of chunk c+3
+// V holds fp32; the wave that multiplies a position splits its A fragment into bf16 pieces right at the load
+// (every V element belongs to exactly one wave's fragment, so nothing is split twice).
+// ABL: compile-time ablation mask for the diagnostic build (results are wrong, only timing matters; always 0 in
+// the product): 1 weights loaded once, 2 no input transform, 4 no staging (loads + raw write), 8 no matrix work,
+// 16 no epilogue.
+template <int UPS, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_wino_bf16x3_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* raw = lds;
-  unsigned char* V = reinterpret_cast<unsigned char*>(lds) + RAW_BYTES;
+  float* V = lds + RAW_FLOATS;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -106,13 +132,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_bf16x3_kernel(ConvArgs p) {
       inside |= (ok ? 1u : 0u) << i;
     }
   }
-  // this thread's two transform items (channel quad cq, tile, row xi): LDS offsets are chunk-invariant
+  // this thread's two transform items (tile, channel quad cq, row xi): LDS offsets are chunk-invariant
   int rd_a[2], rd_b[2], wr_v[2];
   float sgn[2];
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int item = tid + it * 256;
-    const int cq = item & 3, tile = (item >> 2) & 31, xi = item >> 7;
+    const int tile = item & 31, cq = (item >> 5) & 3, xi = item >> 7;
     const int ty = tile >> 3, tx = tile & 7;
     // rows of d that enter row xi of B^T d:  xi0: d0-d2, xi1: d1+d2, xi2: d2-d1, xi3: d1-d3
     const int ra_ = (xi == 0) ? 0 : (xi == 2 ? 2 : 1);
@@ -120,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_bf16x3_kernel(ConvArgs p) {
     sgn[it] = (xi == 1) ? 1.f : -1.f;
     rd_a[it] = ((2 * ty + ra_) * IN_W + 2 * tx) * RAWP + cq * 4;
     rd_b[it] = ((2 * ty + rb_) * IN_W + 2 * tx) * RAWP + cq * 4;
-    wr_v[it] = (((xi * 4) * 3) * NT + tile) * 32 + cq * 8;  // position 4*xi + nu is nu * 3*NT*32 bytes further
+    wr_v[it] = (((xi * 4) * 4 + cq) * NT + tile) * 4;  // position 4*xi + nu, k quarter cq
   }
   const int wr_raw0 = (tid >> 2) * RAWP + c4 * 4;  // slot i lives 64 pixels further
 
@@ -133,6 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_bf16x3_kernel(ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[q][nb][r] = 0.f;
 
   const int nchunks = p.nch0 + p.nch1;
+  const int last = nchunks - 1;
   // packed U: [nt][chunk][pos 16][nb 2][piece 3][lane 64] x 16 B; this wave's positions are 4*wave .. 4*wave + 3
   const uint4* wu = reinterpret_cast<const uint4*>(p.wpack) + ((size_t)nt * nchunks * 16 + wave * 4) * POS_U4 + lane;
   const int nlin = nchunks * 4;  // (chunk, position-of-this-wave) pairs in matrix-phase order
@@ -143,7 +170,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_bf16x3_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) bq[buf][i] = src[i * 64];
   };
-  const unsigned char* va = V + (wave * 4 * 3 * NT + l31) * 32 + half * 16;
+  // A fragment of position 4*wave + q: lane (tile l31, K half) reads k quarters 2*half, 2*half + 1
+  const float* va = V + ((wave * 16 + 2 * half) * NT + l31) * 4;
 
   float4 v[NLOAD];
   float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -160,40 +188,31 @@ __global__ __launch_bounds__(256, 2) void conv_wino_bf16x3_kernel(ConvArgs p) {
       cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + cc);
     }
   };
-
-  issue_chunk_loads(0);
-  load_b(0, 0);
-
-  for (int ch = 0; ch < nchunks; ++ch) {
-    // ---- 1. registers -> (prologue SiLU(a*x+b)) -> raw LDS tile
-    {
-      const bool s1 = ch >= p.nch0;
-      const bool pro = (p.in_coef != nullptr) && !s1;
-      const int Csrc = s1 ? p.C1 : p.C0;
-      const bool cvalid = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4 < Csrc;
-      const unsigned m = cvalid ? inside : 0u;
+  // registers (chunk ch) -> (prologue SiLU(a*x+b)) -> raw LDS tile
+  auto raw_write = [&](int ch) {
+    const bool s1 = ch >= p.nch0;
+    const bool pro = (p.in_coef != nullptr) && !s1;
+    const int Csrc = s1 ? p.C1 : p.C0;
+    const bool cvalid = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4 < Csrc;
+    const unsigned m = cvalid ? inside : 0u;
 #pragma unroll
-      for (int i = 0; i < NLOAD; ++i) {
-        if (i < NLOAD - 1 || ((tid + i * 256) >> 2) < IN_PIX) {
-          float4 x = v[i];
-          if (!((m >> i) & 1u)) {
-            x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly zero: it pads the ACTIVATED tensor
-          } else if (pro) {
-            x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
-            x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
-            x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
-            x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
-          }
-          st4(raw + wr_raw0 + i * (64 * RAWP), x);
+    for (int i = 0; i < NLOAD; ++i) {
+      if (i < NLOAD - 1 || ((tid + i * 256) >> 2) < IN_PIX) {
+        float4 x = v[i];
+        if (!((m >> i) & 1u)) {
+          x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding stays exactly zero: it pads the ACTIVATED tensor
+        } else if (pro) {
+          x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
+          x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
+          x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
+          x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
         }
+        st4(raw + wr_raw0 + i * (64 * RAWP), x);
       }
     }
-    __syncthreads();  // raw published; every wave has also left the previous matrix phase (V is free)
-    // next chunk's halo (last chunk: a harmless re-load of itself keeps the vmcnt bookkeeping exact)
-    issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- 2. input transform V = B^T d B (packed fp32 adds), split into bf16 pieces
+  };
+  // input transform V = B^T d B of the chunk in `raw` -> V[buf], two items per thread
+  auto transform = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       const float* pa = raw + rd_a[it];
@@ -206,42 +225,80 @@ __global__ __launch_bounds__(256, 2) void conv_wino_bf16x3_kernel(ConvArgs p) {
         w[c].lo = da.lo + sg * db.lo;
         w[c].hi = da.hi + sg * db.hi;
       }
-      unsigned char* vo = V + wr_v[it];  // V[xi][0..3] = w0-w2, w1+w2, w2-w1, w1-w3
-      split_store(vo, w[0] - w[2]);
-      split_store(vo + 1 * (3 * NT * 32), w[1] + w[2]);
-      split_store(vo + 2 * (3 * NT * 32), w[2] - w[1]);
-      split_store(vo + 3 * (3 * NT * 32), w[1] - w[3]);
+      float* vo = V + buf * V_FLOATS + wr_v[it];  // V[xi][0..3] = w0-w2, w1+w2, w2-w1, w1-w3
+      stf4(vo, w[0] - w[2]);
+      stf4(vo + 1 * (4 * NT * 4), w[1] + w[2]);
+      stf4(vo + 2 * (4 * NT * 4), w[2] - w[1]);
+      stf4(vo + 3 * (4 * NT * 4), w[1] - w[3]);
     }
-    __syncthreads();  // V published
+  };
 
-    // ---- 3. matrix phase: the four positions of row `wave`: M[32 tiles][64 cout] += V[tiles][k] U[k][cout]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      load_b((q & 1) ^ 1, ch * 4 + q + 1);  // next position's weights (possibly the next chunk's first)
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 a[3];
-#pragma unroll
-      for (int s = 0; s < 3; ++s) a[s] = *reinterpret_cast<const bf16x8*>(va + (q * 3 + s) * (NT * 32));
-#define DMH_TERM(sa, sb)                                                                                              \
-  acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sa], __builtin_bit_cast(bf16x8, bq[q & 1][sb]), acc[q][0], 0, \
-                                                      0, 0);                                                          \
-  acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sa], __builtin_bit_cast(bf16x8, bq[q & 1][3 + sb]), acc[q][1], \
-                                                      0, 0, 0);
-      DMH_TERM(2, 0)  // smallest terms first
-      DMH_TERM(0, 2)
-      DMH_TERM(1, 1)
-      DMH_TERM(1, 0)
-      DMH_TERM(0, 1)
-      DMH_TERM(0, 0)
-#undef DMH_TERM
-    }
-    __builtin_amdgcn_sched_barrier(0);
+#define DMH_TERM(q, sa, sb)                                                                                       \
+  acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sa], __builtin_bit_cast(bf16x8, bq[(q) & 1][sb]), acc[q][0], \
+                                                      0, 0, 0);                                                   \
+  acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[sa], __builtin_bit_cast(bf16x8, bq[(q) & 1][3 + sb]),     \
+                                                      acc[q][1], 0, 0, 0);
+  // position 4*wave + q of chunk c: M[32 tiles][64 cout] += V[tiles][k] U[k][cout], smallest terms first
+#define DMH_POSITION(c, q)                                                         \
+  {                                                                                \
+    if (!(ABL & 1)) load_b(((q) & 1) ^ 1, (c) * 4 + (q) + 1); /* next position's weights */ \
+    __builtin_amdgcn_sched_barrier(0x38F);    /* memory loads stay up here */      \
+    const float* vb = va + ((c) & 1) * V_FLOATS + (q) * (4 * NT * 4);              \
+    const float4 f0 = ld4(vb), f1 = ld4(vb + NT * 4);                              \
+    bf16x8 a[3];                                                                   \
+    split8(f0, f1, a);                                                             \
+    DMH_TERM(q, 2, 0)                                                              \
+    DMH_TERM(q, 0, 2)                                                              \
+    DMH_TERM(q, 1, 1)                                                              \
+    DMH_TERM(q, 1, 0)                                                              \
+    DMH_TERM(q, 0, 1)                                                              \
+    DMH_TERM(q, 0, 0)                                                              \
   }
+
+  auto stage = [&](int c, auto TR, auto RW) {
+    if constexpr (decltype(TR)::value && !(ABL & 2)) transform((c & 1) ^ 1);
+    if constexpr (!(ABL & 8)) {
+      DMH_POSITION(c, 0)
+      DMH_POSITION(c, 1)
+    }
+    __syncthreads();  // raw is free again (and V[(c+1)&1] is complete)
+    if constexpr (decltype(RW)::value && !(ABL & 4)) {
+      raw_write(c + 2);
+      issue_chunk_loads(c + 3 < nchunks ? c + 3 : last);
+    }
+    if constexpr (!(ABL & 8)) {
+      DMH_POSITION(c, 2)
+      DMH_POSITION(c, 3)
+    }
+    __syncthreads();  // raw of chunk c+2 published; V[c & 1] is free
+  };
+
+  // ---- pipeline fill
+  issue_chunk_loads(0);
+  load_b(0, 0);
+  if (ABL & 1) load_b(1, 1);
+  raw_write(0);
+  __syncthreads();
+  issue_chunk_loads(1 < nchunks ? 1 : last);
+  transform(0);
+  __syncthreads();
+  if (nchunks > 1) raw_write(1);
+  issue_chunk_loads(2 < nchunks ? 2 : last);
+  __syncthreads();
+
+  for (int c = 0; c < nchunks - 2; ++c) stage(c, True_{}, True_{});
+  if (nchunks >= 2) stage(nchunks - 2, True_{}, False_{});
+  stage(nchunks - 1, False_{}, False_{});
+#undef DMH_POSITION
+#undef DMH_TERM
 
   // ---- output transform Y = A^T M A.  This wave holds row xi = wave of M: contract over nu in registers,
   //      Z[xi][j] = sum_nu A[nu][j] M[xi][nu], exchange rows through LDS, contract over xi while reading.
-  __syncthreads();  // every wave has left the last matrix phase: LDS becomes the exchange buffer
-  float* Z = lds;
+  float* Z = lds;  // (the last stage ended on a barrier: LDS is free)
+  if constexpr (ABL & 16) {
+    if (acc[0][0][0] + acc[1][1][3] + acc[2][0][5] + acc[3][1][7] == 12345.f) p.out[0] = 0.f;  // keep the matrix work alive
+    return;
+  }
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -356,6 +413,29 @@ int dmh_winobx_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
     attr = true;
   }
   dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
+#ifdef DMH_STAMPS
+  if (const char* e = getenv("DMH_BX_ABL")) {
+#define DMH_ABL_CASE(n)                                                                                          \
+  case n:                                                                                                        \
+    (void)hipFuncSetAttribute((const void*)conv_wino_bf16x3_kernel<0, n>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              LDS_BYTES);                                                                        \
+    hipLaunchKernelGGL((conv_wino_bf16x3_kernel<0, n>), grid, dim3(256), LDS_BYTES, st, a);                      \
+    return DMH_OK;
+    switch (atoi(e)) {
+      DMH_ABL_CASE(1)
+      DMH_ABL_CASE(2)
+      DMH_ABL_CASE(4)
+      DMH_ABL_CASE(6)
+      DMH_ABL_CASE(8)
+      DMH_ABL_CASE(16)
+      DMH_ABL_CASE(7)
+      DMH_ABL_CASE(23)
+      DMH_ABL_CASE(14)
+      DMH_ABL_CASE(30)
+    }
+#undef DMH_ABL_CASE
+  }
+#endif
   if (d->upsample2)
     hipLaunchKernelGGL((conv_wino_bf16x3_kernel<1>), grid, dim3(256), LDS_BYTES, st, a);
   else

@@ -35,15 +35,20 @@ def test_library_loads_and_exports_every_symbol():
 def test_pure_host_entry_points():
     from dmhomo_amd import _lib
     lib = _lib.lib()
-    # 3x3: Winograd image = ceil(Cout/64) * chunks(16 ch) * 16 positions * 64 cout * 16 k  (default tiling);
-    # implicit-GEMM image = ceil(Cout/64) * chunks * 9 taps * 64 * KC when DMH_CONV3_VARIANT selects it
-    assert lib.dmh_conv_pack_floats(64, 64, 0, 3, 3) in (1 * 4 * 16 * 64 * 16, 1 * 2 * 9 * 64 * 32)
-    assert lib.dmh_conv_pack_floats(512, 512, 256, 3, 3) in (8 * (32 + 16) * 16 * 64 * 16, 8 * (16 + 8) * 9 * 64 * 32)
-    assert lib.dmh_conv_pack_floats(384, 64, 0, 1, 1) == 6 * 2 * 1 * 64 * 32
+    # default (fp16-piece kernel, 3x3 and 1x1): ceil(Cout/64) * chunks(32 ch) * taps * 2 k-steps * 6 fragments of 1 KB
+    # (= 1536 floats per k-step) + 64 per-channel scales per 64-channel block; other DMH_CONV3_VARIANTs pack differently
+    def f16x3(cout, c0, c1, taps):
+        nt = (cout + 63) // 64
+        return nt * ((c0 + 31) // 32 + (c1 + 31) // 32) * taps * 2 * 1536 + nt * 64
+    import os
+    if os.environ.get('DMH_CONV3_VARIANT', '9') == '9':
+        assert lib.dmh_conv_pack_floats(64, 64, 0, 3, 3) == f16x3(64, 64, 0, 9)
+        assert lib.dmh_conv_pack_floats(512, 512, 256, 3, 3) == f16x3(512, 512, 256, 9)
+        assert lib.dmh_conv_pack_floats(384, 64, 0, 1, 1) == f16x3(384, 64, 0, 1)
+        assert lib.dmh_conv_tiles(128, 128, 3, 1) == 128 and lib.dmh_conv_tiles(128, 128, 1, 1) == 128   # 8x16 stat tiles
     assert lib.dmh_conv_pack_floats(64, 12, 0, 7, 7) == 1 * 1 * 49 * 64 * 16
     assert lib.dmh_conv_pack_floats(128, 64, 0, 4, 4) == 2 * 4 * 16 * 64 * 16
-    assert lib.dmh_conv_tiles(128, 128, 3, 1) in (64, 128)      # 16x16 or 8x16 output tiles (3x3 tiling variant)
-    assert lib.dmh_conv_tiles(128, 128, 1, 1) == 64 and lib.dmh_conv_tiles(64, 64, 4, 2) == 32
+    assert lib.dmh_conv_tiles(64, 64, 4, 2) == 32
     assert lib.dmh_linattn_splits(16384) == 128 and lib.dmh_linattn_splits(4) == 1
     assert lib.dmh_linattn_partial_floats(2, 256) == 2 * 2 * 4 * 1088
 

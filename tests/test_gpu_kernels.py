@@ -68,6 +68,39 @@ def test_conv2d(ops, case):
     close(name + ' stats.sumsq', tot[..., 1], (ref.double() ** 2).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
 
 
+RANGE_CASES = [  # name, activation scale per 32-channel group, weight scale per output-channel half
+    ('unit', (1, 1, 1, 1), (1, 1)),
+    ('tiny activations', (1e-6, 1e-6, 1e-6, 1e-6), (1, 1)),
+    ('huge activations', (1e6, 1e6, 1e6, 1e6), (1, 1)),
+    ('growing chunks', (1e-4, 1e-2, 1, 1e3), (1, 1)),       # every chunk raises the running block maximum
+    ('shrinking chunks', (1e3, 1, 1e-2, 1e-4), (1, 1)),
+    ('mixed weights', (1, 1e-3, 1e2, 1), (1e-5, 1e4)),
+    ('beyond fp16 range', (1e20, 1e20, 1e20, 1e20), (1e-12, 1e-12)),
+]
+
+
+@pytest.mark.parametrize('case', RANGE_CASES, ids=[c[0] for c in RANGE_CASES])
+def test_conv3x3_dynamic_range(ops, case):
+    """the 3x3 kernel keeps fp32 accuracy (error relative to the output scale, against an fp64 convolution) whatever
+    the magnitudes of activations and weights — the 16-bit-piece kernels rescale blockwise, nothing may overflow"""
+    name, ascale, wscale = case
+    B, H, W, C, Co = 2, 24, 40, 128, 128
+    x = rand((B, C, H, W), 31)
+    x = x * torch.tensor(ascale, dtype=torch.float32).repeat_interleave(32)[None, :, None, None]
+    w = rand((Co, C, 3, 3), 32, (1.0 / (C * 9)) ** 0.5)
+    w = w * torch.tensor(wscale, dtype=torch.float32).repeat_interleave(64)[:, None, None, None]
+    b = rand((Co,), 33, 0.1) * float(max(ascale)) * torch.tensor(wscale).repeat_interleave(64)
+    pc = ops.PackedConv(w.to(dev()), b.to(dev()), C)
+    got = nchw(ops.conv2d(pc, nhwc(x))).double()
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1)
+    # per output-channel half: error relative to that half's output scale (same bar as an fp32 fma chain, K = 1152)
+    for h in range(2):
+        g, r = got[:, h * 64:(h + 1) * 64], ref[:, h * 64:(h + 1) * 64]
+        rel = ((g - r).abs().max() / r.abs().max()).item()
+        print(f'[parity] conv3x3 range {name} half {h}: rel_to_max={rel:.3e} ref_absmax={r.abs().max().item():.3e}')
+        assert torch.isfinite(g).all() and rel < 2e-6, (name, h, rel)
+
+
 def test_conv2d_prologue_and_residual(ops):
     """GN-apply+SiLU prologue (zero padding applies to the ACTIVATED tensor) and both residual epilogues"""
     B, H, W, C, Co = 2, 18, 21, 32, 48

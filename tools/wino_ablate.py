@@ -21,8 +21,14 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
             ops.conv2d(pc, x)
         e1.record(); torch.cuda.synchronize()
         print(f'  {C}->{C}@{H}: {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us')
+elif os.environ.get('DMH_WBX_SWEEP'):
+    for abl, name in ((0, 'full'), (1, 'weights loaded once'), (2, 'no input transform'), (4, 'no staging'), (6, 'no staging, no transform'),
+                      (8, 'no matrix work'), (16, 'no epilogue'), (7, 'matrix work + epilogue only'), (23, 'matrix work only (MFMA + split + A reads)'),
+                      (14, 'epilogue only'), (30, 'empty')):
+        print(f'wino bf16x3 ABL={abl} ({name})', flush=True)
+        subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, DMH_BX_ABL=str(abl), DMH_CONV3_VARIANT='8'))
 elif os.environ.get('DMH_BX_SWEEP'):
-    for abl, name in (('0', 'full'), ('1', 'no weight loads'), ('2', 'A fragments once per chunk'), ('3', 'neither: MFMA + staging + epilogue')):
+    for abl, name in (('0', 'full'), ('4', 'three terms only'), ('7', 'three terms, no operand traffic')):
         print(f'bf16x3 ABL={abl} ({name})', flush=True)
         subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, DMH_BX_ABL=abl, DMH_CONV3_VARIANT='7'))
 else:
