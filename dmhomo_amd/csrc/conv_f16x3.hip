@@ -12,7 +12,7 @@
 //                h2 = fp16((xs - h1) * 2^11)         the next 11 bits; the subtraction is exact, the scaled residual
 //                                                    has the magnitude of h1, so it never falls into fp16 subnormals
 //   weights      ws = w * 2^k          k per output channel: max |w| of the channel sits in [2^14, 2^15)   (pack time)
-//                g1 = fp16(ws),  g2 = fp16(ws - g1),  g1s = fp16(g1 * 2^-11)
+//                g1 = fp16(ws),  g2 = fp16(ws - g1)  (streamed),   g1s = g1 * 2^-11  (derived in registers)
 //   product      x*w*s*2^k = h1*g1 + h1*g2 + h2*g1s + (h2*g2*2^-11 + rounding of the pieces) : the dropped part is
 //                <= 2^-22 relative, every fp16*fp16 product is exact in fp32, the MFMA accumulates in fp32
 //   output       y = acc / s * 2^-k + bias
@@ -44,7 +44,7 @@ namespace {
 
 constexpr int KC = 32;                // input channels per chunk
 constexpr int PITCH = 144;            // LDS bytes per staged pixel: 2 planes x 32 fp16 + 16 (odd multiple of 16 B)
-constexpr int STEP_U4 = 6 * 64;       // uint4 per (chunk, tap, k16): 2 column blocks x 3 planes x 64 lanes
+constexpr int STEP_U4 = 4 * 64;       // uint4 per (chunk, tap, k16): 2 column blocks x 2 planes (g1, g2) x 64 lanes
 
 template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
 struct F16Cfg {
@@ -55,7 +55,11 @@ struct F16Cfg {
   static constexpr int IN_PIX = IN_H * IN_W;
   static constexpr int NLOAD = (IN_PIX * 8 + 255) / 256;
   static constexpr int PAD = (S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0);
-  static constexpr int IN_BYTES = IN_PIX * PITCH;
+  // row pitch: a multiple of 256 B.  ds_read_b128 serves lanes in groups of 16 that pair 8 pixels of one tile row
+  // with the complementary 8 of the next row (MI355X_MICROARCH.md, LDS): with rows 0 mod 256 B apart and an odd
+  // pixel pitch (in 16 B units) the 16 lanes of a group fall on 16 distinct 16 B bank groups
+  static constexpr int ROWP = (IN_W * PITCH + 255) / 256 * 256;
+  static constexpr int IN_BYTES = IN_H * ROWP;
   static constexpr int EPI_BYTES = 4 * 32 * EpilogueRows::EP * 4;
   static constexpr int TILE_BYTES = IN_BYTES > EPI_BYTES ? IN_BYTES : EPI_BYTES;
   static constexpr int LDS_BYTES = TILE_BYTES + 16;  // + the two block-maximum slots
@@ -68,7 +72,7 @@ __device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x)
 template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   using Cfg = F16Cfg<KH, KW, S, UPS, TH, TW, WM, WN>;
-  constexpr int IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, NLOAD = Cfg::NLOAD, NTAPS = KH * KW;
+  constexpr int IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, NLOAD = Cfg::NLOAD, NTAPS = KH * KW, ROWP = Cfg::ROWP;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned char* in_tile = reinterpret_cast<unsigned char*>(lds);
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   for (int mb = 0; mb < 2; ++mb) {
     const int r = wm * 64 + mb * 32 + l31;
     const int py = r / TW, px = r % TW;
-    arow[mb] = ((py * S) * IN_W + px * S) * PITCH + half * 16;
+    arow[mb] = (py * S) * ROWP + (px * S) * PITCH + half * 16;
   }
 
   floatx16 acc[2][2];
@@ -117,26 +121,31 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   const int nsteps = nchunks * NTAPS * 2;
   const uint4* wbase = reinterpret_cast<const uint4*>(p.wpack) + (size_t)nt * nsteps * STEP_U4 + lane;
 
-  // B fragments of one K step: [column block][plane g1, g2, g1s]; double buffered across steps
-  uint4 bq[2][6];
+  // B fragments of one K step: [column block][plane g1, g2]; NB buffers rotate over the K steps, so the loads
+  // run NB - 1 steps (two for 3x3) ahead of their use
+  constexpr int NSTEP = NTAPS * 2;                  // K steps per chunk
+  constexpr int NB = (NSTEP % 3 == 0) ? 3 : 2;      // NSTEP % NB == 0: a step's buffer index is static
+  uint4 bq[NB][4];
   auto load_b = [&](int buf, int step) {
     const uint4* src = wbase + (size_t)(step < nsteps ? step : nsteps - 1) * STEP_U4;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) bq[buf][i] = src[i * 64];
+    for (int i = 0; i < 4; ++i) bq[buf][i] = src[i * 64];
   };
-  load_b(0, 0);
+#pragma unroll
+  for (int i = 0; i < NB - 1; ++i) load_b(i, i);
 
   // input (halo) tile of one channel chunk: global -> registers, issued one chunk ahead.  Unconditional loads
   // from clamped addresses + a validity mask (see conv.hip) keep them in flight under counted waits.
   const int c4 = tid & 7;
   float4 v[NLOAD];
   float4 ca, cb;
-  int poff[NLOAD];
+  int poff[NLOAD], wroff[NLOAD];
   unsigned inside = 0;
 #pragma unroll
   for (int i = 0; i < NLOAD; ++i) {
     const int pix = (tid + i * 256) >> 3;
     const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
+    wroff[i] = (pixc / IN_W) * ROWP + (pixc % IN_W) * PITCH + c4 * 8;  // staging slot in the LDS tile
     const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
     const bool ok = pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
     const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
@@ -160,7 +169,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     }
   };
   issue_chunk_loads(0);
-  const int wr0 = (tid >> 3) * PITCH + c4 * 8;  // staging slot 0; slot i is 32 pixels further
   __syncthreads();                              // block-maximum slots are zeroed
 
   int e_run = 16;  // biased exponent of the running block maximum (clamped to [16, 254]); uniform
@@ -208,6 +216,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
           for (int r = 0; r < 16; ++r) acc[mb][nb][r] *= f;
     }
     // ---- split into two fp16 planes -> LDS
+#ifdef DMH_STAMPS
+    if (!(p.ablate & 1))
+#endif
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       if ((i + 1) * 256 <= IN_PIX * 8 || ((tid + i * 256) >> 3) < IN_PIX) {
@@ -215,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
         const half4 h1 = __builtin_convertvector(xs, half4);
         const float4v rs = (xs - __builtin_convertvector(h1, float4v)) * 2048.f;
         const half4 h2 = __builtin_convertvector(rs, half4);
-        unsigned char* dst = in_tile + wr0 + i * 32 * PITCH;
+        unsigned char* dst = in_tile + wroff[i];
         *reinterpret_cast<half4*>(dst) = h1;
         *reinterpret_cast<half4*>(dst + 64) = h2;
       }
@@ -225,25 +236,37 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
     __builtin_amdgcn_sched_barrier(0);
 
-    for (int tap = 0; tap < NTAPS; ++tap) {
-      const int kh = tap / KW, kw = tap % KW;
-      const unsigned char* at = in_tile + (kh * IN_W + kw) * PITCH;
+    // A fragments [row block][plane]
+    half8 a[2][2];
+    auto read_a = [&](int st) {
+      const int tap = st >> 1, k16 = st & 1;
+      const unsigned char* at = in_tile + (tap / KW) * ROWP + (tap % KW) * PITCH + k16 * 32;
 #pragma unroll
-      for (int k16 = 0; k16 < 2; ++k16) {
-        load_b(k16 ^ 1, step + 1);  // prefetch the next K step's weights (other buffer)
-        __builtin_amdgcn_sched_barrier(0);
-        half8 a[2][2];
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int pl = 0; pl < 2; ++pl) a[mb][pl] = *reinterpret_cast<const half8*>(at + arow[mb] + pl * 64);
+    };
+#ifdef DMH_STAMPS
+    if (!(p.ablate & 2))
+#endif
+    {
 #pragma unroll
-          for (int s = 0; s < 2; ++s) a[mb][s] = *reinterpret_cast<const half8*>(at + arow[mb] + s * 64 + k16 * 32);
-#define DMH_TERM(sa, sb)                                                                                             \
-  _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc[mb][nb] =  \
-      __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][sa], __builtin_bit_cast(half8, bq[k16][nb * 3 + sb]), acc[mb][nb], 0, \
-                                             0, 0);
-        DMH_TERM(1, 2)  // h2 * g1s   (smallest terms first)
-        DMH_TERM(0, 1)  // h1 * g2
-        DMH_TERM(0, 0)  // h1 * g1
+      for (int st = 0; st < NSTEP; ++st) {
+        load_b((st + NB - 1) % NB, step + NB - 1);  // weights of the step NB - 1 ahead
+        __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the loads next to their use)
+        read_a(st);
+        // g1s = g1 * 2^-11 is derived here (4 packed fp16 multiplies per fragment) instead of being streamed:
+        // a third less weight traffic on the CU's 64 B/clk vector-memory path
+        half8 g1s[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          g1s[nb] = __builtin_bit_cast(half8, bq[st % NB][nb * 2]) * (_Float16)(1.0f / 2048.0f);
+#define DMH_TERM(pl, bexpr)                                                                                       \
+  _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = \
+      __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
+        DMH_TERM(1, g1s[nb])                                                 // h2 * g1s   (smallest terms first)
+        DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2 + 1]))      // h1 * g2
+        DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h1 * g1
 #undef DMH_TERM
         ++step;
       }
@@ -252,6 +275,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   }
 
   // ---- epilogue: accumulators / block scale -> LDS transpose -> rows (conv_args.h applies 2^-k per channel)
+#ifdef DMH_STAMPS
+  if (!(p.ablate & 4))
+#endif
   {
     constexpr int EP = EpilogueRows::EP;
     const float inv_s = __uint_as_float((unsigned)(e_run - 14) << 23);  // 1 / sc
@@ -292,8 +318,8 @@ __global__ __launch_bounds__(64) void f16x3_wscale_kernel(const float* __restric
   }
 }
 
-// fp16 element index: ((((((nt * nchunks + ch) * NTAPS + tap) * 2 + k16) * 2 + nb) * 3 + plane) * 64 + lane) * 8 + j
-//   -> plane (g1, g2, g1s) of w[o = nt*64 + nb*32 + (lane & 31)][c = chunk channel k16*16 + (lane >> 5)*8 + j][tap] * 2^k
+// fp16 element index: ((((((nt * nchunks + ch) * NTAPS + tap) * 2 + k16) * 2 + nb) * 2 + plane) * 64 + lane) * 8 + j
+//   -> plane (g1, g2) of w[o = nt*64 + nb*32 + (lane & 31)][c = chunk channel k16*16 + (lane >> 5)*8 + j][tap] * 2^k
 __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const float* __restrict__ oscale,
                                          _Float16* __restrict__ wp, int Cout, int C0, int C1, int NTAPS, int nch0,
                                          int nch1, int64_t total) {
@@ -304,8 +330,8 @@ __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const floa
   r /= 8;
   const int lane = r % 64;
   r /= 64;
-  const int plane = r % 3;
-  r /= 3;
+  const int plane = r % 2;
+  r /= 2;
   const int nb = r % 2;
   r /= 2;
   const int k16 = r % 2;
@@ -330,8 +356,7 @@ __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const floa
   if (ok && o < Cout) ws = w[((size_t)o * (C0 + C1) + c) * NTAPS + tap] / oscale[o];  // exact: a power of two
   const _Float16 g1 = (_Float16)ws;
   const _Float16 g2 = (_Float16)(ws - (float)g1);
-  const _Float16 g1s = (_Float16)((float)g1 * (1.f / 2048.f));
-  wp[idx] = plane == 0 ? g1 : (plane == 1 ? g2 : g1s);
+  wp[idx] = plane == 0 ? g1 : g2;
 }
 
 static int64_t f16x3_frag_floats(int Cout, int C0, int C1, int KH, int KW) {
@@ -360,6 +385,9 @@ static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   using Cfg = F16Cfg<KH, KW, S, UPS, TH, TW, WM, WN>;
   ConvArgs a = fill_conv_args(d, Hout, Wout, KC, TH, TW);
   a.oscale = d->wpack + f16x3_frag_floats(d->Cout, a.C0, a.C1, KH, KW);
+#ifdef DMH_STAMPS
+  if (const char* e = getenv("DMH_WINO_ABLATE")) a.ablate = atoi(e);
+#endif
   auto kern = conv_f16x3_kernel<KH, KW, S, UPS, TH, TW, WM, WN>;
   static bool attr_set = false;
   if (!attr_set) {

@@ -35,11 +35,11 @@ def test_library_loads_and_exports_every_symbol():
 def test_pure_host_entry_points():
     from dmhomo_amd import _lib
     lib = _lib.lib()
-    # default (fp16-piece kernel, 3x3 and 1x1): ceil(Cout/64) * chunks(32 ch) * taps * 2 k-steps * 6 fragments of 1 KB
-    # (= 1536 floats per k-step) + 64 per-channel scales per 64-channel block; other DMH_CONV3_VARIANTs pack differently
+    # default (fp16-piece kernel, 3x3 and 1x1): ceil(Cout/64) * chunks(32 ch) * taps * 2 k-steps * 4 fragments of 1 KB
+    # (= 1024 floats per k-step) + 64 per-channel scales per 64-channel block; other DMH_CONV3_VARIANTs pack differently
     def f16x3(cout, c0, c1, taps):
         nt = (cout + 63) // 64
-        return nt * ((c0 + 31) // 32 + (c1 + 31) // 32) * taps * 2 * 1536 + nt * 64
+        return nt * ((c0 + 31) // 32 + (c1 + 31) // 32) * taps * 2 * 1024 + nt * 64
     import os
     if os.environ.get('DMH_CONV3_VARIANT', '9') == '9':
         assert lib.dmh_conv_pack_floats(64, 64, 0, 3, 3) == f16x3(64, 64, 0, 9)

@@ -32,6 +32,8 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', type=str, default='')
     ap.add_argument('--batch', type=int, default=0, help='override the row count B')
+    ap.add_argument('--zeros', action='store_true', help='all-zero activations and weights: the same instruction stream at '
+                    'minimal switching power; a large speed-up against random data means the kernel sits on the power limit')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     for name, B, H, W, C0, C1, Cout, k, stride, ups, pro in SHAPES:
@@ -43,6 +45,11 @@ def main():
         pc = ops.PackedConv(w, torch.randn(Cout, device=dev), C0, C1, stride, ups)
         s0 = torch.randn((B, H, W, C0), device=dev)
         s1 = torch.randn((B, H, W, C1), device=dev) if C1 else None
+        if args.zeros:
+            pc = ops.PackedConv(torch.zeros_like(w), torch.zeros(Cout, device=dev), C0, C1, stride, ups)
+            s0.zero_()
+            if s1 is not None:
+                s1.zero_()
         coef = None
         if pro:
             coef = torch.stack([1 + 0.1 * torch.randn(B, C0, device=dev), 0.1 * torch.randn(B, C0, device=dev)], 1).contiguous()

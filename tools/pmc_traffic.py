@@ -18,7 +18,7 @@ write_kib, n2 = per_launch(sys.argv[2], 'WRITE_SIZE', sys.argv[3])
 out = {'kernel': sys.argv[3], 'launches': n1,
        'fetch_bytes_per_launch': 2 * fetch_kib * 1024, 'write_bytes_per_launch': write_kib * 1024,
        'hbm_bytes_per_launch': 2 * fetch_kib * 1024 + write_kib * 1024,
-       'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 '
+       'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --s_step 2 '
                '--cfg-mode batched`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request)'}
 json.dump(out, open(sys.argv[4], 'w'), indent=1)
 print(out)

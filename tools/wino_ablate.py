@@ -32,7 +32,7 @@ elif os.environ.get('DMH_BX_SWEEP'):
         print(f'bf16x3 ABL={abl} ({name})', flush=True)
         subprocess.run([sys.executable, __file__, 'child'], env=dict(os.environ, DMH_BX_ABL=abl, DMH_CONV3_VARIANT='7'))
 else:
-    v7 = os.environ.get('DMH_CONV3_VARIANT') == '7'
+    v7 = os.environ.get('DMH_CONV3_VARIANT') in ('7', '9')
     for wide in (('1',) if v7 else ('0', '1')):
         for abl, name in (('0', 'full'), ('1', 'no staging/transform'), ('2', 'no matrix phase'), ('3', 'neither (loads+epilogue only)')) + \
                 ((('4', 'no epilogue'), ('5', 'matrix phase only'), ('6', 'staging only'), ('7', 'input loads only')) if v7 else ()):
