@@ -192,7 +192,7 @@ def main():
                 with open(tpath) as f:
                     traffic = json.load(f)
             res['roofline'] = {
-                'kernel': 'conv_f16x3_kernel<3,3,...> (3x3 conv, implicit GEMM, 3 x v_mfma_f32_32x32x16_f16 per fp32 '
+                'kernel': 'conv_f16x3_kernel<3,3,...> (3x3 conv, implicit GEMM, 3 x v_mfma_f32_16x16x32_f16 per fp32 '
                           'product block, fp32 accumulate)',
                 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': ach / PEAK_FP32_MFMA_TFLOPS,

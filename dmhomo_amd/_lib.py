@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdmhomo_hip.so')
+# DMH_LIB_PATH: development knob for A/B runs of two builds in one process environment (same GPU, same clocks)
+LIB_PATH = os.environ.get('DMH_LIB_PATH') or os.path.join(_HERE, 'libdmhomo_hip.so')
 
 c_f32p = C.c_void_p
 c_i64 = C.c_int64

@@ -20,7 +20,9 @@
 // construction.  Against an fp64 convolution the error is that of the fp32-MFMA kernels (fp32 accumulation
 // rounding dominates both): tests/test_gpu_kernels.py.
 //
-//   M = output pixels: each wave owns 64 (two 32-row blocks);  N = 64 output channels per wave (two 32 blocks)
+//   M = output pixels: each wave owns 64 (four 16-row blocks = four tile rows);  N = 64 output channels per wave;
+//       v_mfma_f32_16x16x32_f16 (K = the 32 channels of a chunk): at equal cycles per FLOP this shape draws less
+//       power than 32x32x16, and the kernel is power-limited
 //   workgroup = 4 waves as WM x WN:  4x1 -> 16x16 pixels x 64 cout,   2x2 -> 8x16 pixels x 128 cout
 //   K = taps x input channels in chunks of 32 channels: per chunk the (halo) input tile is staged ONCE into LDS —
 //       through the fused prologue SiLU(a*x+b) when a GroupNorm is pending — as two fp16 planes and reused by
@@ -43,8 +45,8 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int KC = 32;                // input channels per chunk
-constexpr int PITCH = 144;            // LDS bytes per staged pixel: 2 planes x 32 fp16 + 16 (odd multiple of 16 B)
-constexpr int STEP_U4 = 4 * 64;       // uint4 per (chunk, tap, k16): 2 column blocks x 2 planes (g1, g2) x 64 lanes
+constexpr int PITCH = 160;            // LDS bytes per staged pixel: 2 planes x 32 fp16 + 32 (see F16Cfg)
+constexpr int STEP_U4 = 4 * 64;       // uint4 per (chunk, tap, cout half): 2 column blocks x 2 planes (g1, g2) x 64 lanes
 
 template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
 struct F16Cfg {
@@ -55,10 +57,10 @@ struct F16Cfg {
   static constexpr int IN_PIX = IN_H * IN_W;
   static constexpr int NLOAD = (IN_PIX * 8 + 255) / 256;
   static constexpr int PAD = (S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0);
-  // row pitch: a multiple of 256 B.  ds_read_b128 serves lanes in groups of 16 that pair 8 pixels of one tile row
-  // with the complementary 8 of the next row (MI355X_MICROARCH.md, LDS): with rows 0 mod 256 B apart and an odd
-  // pixel pitch (in 16 B units) the 16 lanes of a group fall on 16 distinct 16 B bank groups
-  static constexpr int ROWP = (IN_W * PITCH + 255) / 256 * 256;
+  // An A fragment of v_mfma_f32_16x16x32_f16 is 16 pixels of one tile row x 4 K-groups of 16 B.  ds_read_b128 serves
+  // lanes in groups of 16 that pair 8 pixels of one K-group with the complementary 8 pixels of the next K-group
+  // (MI355X_MICROARCH.md, LDS): with a pixel pitch of 10 x 16 B those 16 lanes fall on 16 distinct 16 B bank groups.
+  static constexpr int ROWP = IN_W * PITCH;
   static constexpr int IN_BYTES = IN_H * ROWP;
   static constexpr int EPI_BYTES = 4 * 32 * EpilogueRows::EP * 4;
   static constexpr int TILE_BYTES = IN_BYTES > EPI_BYTES ? IN_BYTES : EPI_BYTES;
@@ -81,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int half = lane >> 5;
-  const int l31 = lane & 31;
+  const int kg = lane >> 4;   // K group (8 channels) of this lane's A / B fragment slice; row group of its C slice
+  const int l15 = lane & 15;  // fragment row (pixel) / column (output channel)
   const int wm = wave / WN, wn = wave % WN;
 
   int t = blockIdx.x;
@@ -100,30 +102,26 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 
   if (tid < 2) mxslot[tid] = 0u;
 
-  // LDS byte offset of this lane's A rows at tap (0,0), plane 0, k16 step 0
-  int arow[2];
+  // LDS byte offset of this lane's A rows at tap (0,0), plane 0: four 16-pixel row blocks per wave
+  static_assert(TW == 16, "a 16-row MFMA block is one tile row");
+  int arow[4];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int r = wm * 64 + mb * 32 + l31;
-    const int py = r / TW, px = r % TW;
-    arow[mb] = (py * S) * ROWP + (px * S) * PITCH + half * 16;
-  }
+  for (int mb = 0; mb < 4; ++mb) arow[mb] = ((wm * 4 + mb) * S) * ROWP + (l15 * S) * PITCH + kg * 16;
 
-  floatx16 acc[2][2];
+  // accumulators: 4 row blocks x 4 column blocks of 16x16 (C/D layout: row = 4 * (lane >> 4) + r, col = lane & 15)
+  float4v acc[4][4];
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb)
+  for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = float4v{0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = p.nch0 + p.nch1;
   const int nsteps = nchunks * NTAPS * 2;
   const uint4* wbase = reinterpret_cast<const uint4*>(p.wpack) + (size_t)nt * nsteps * STEP_U4 + lane;
 
-  // B fragments of one K step: [column block][plane g1, g2]; NB buffers rotate over the K steps, so the loads
-  // run NB - 1 steps (two for 3x3) ahead of their use
-  constexpr int NSTEP = NTAPS * 2;                  // K steps per chunk
+  // B fragments of one step = (tap, half of the 64 output channels): [column block][plane g1, g2]; NB buffers rotate
+  // over the steps, so the loads run NB - 1 steps (two for 3x3) ahead of their use
+  constexpr int NSTEP = NTAPS * 2;                  // steps per chunk
   constexpr int NB = (NSTEP % 3 == 0) ? 3 : 2;      // NSTEP % NB == 0: a step's buffer index is static
   uint4 bq[NB][4];
   auto load_b = [&](int buf, int step) {
@@ -209,11 +207,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       const int fe = 127 + e_old - e_run;
       const float f = fe > 0 ? __uint_as_float((unsigned)fe << 23) : 0.f;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mb][nb][r] *= f;
+        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] *= f;
     }
     // ---- split into two fp16 planes -> LDS
 #ifdef DMH_STAMPS
@@ -236,13 +232,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
     __builtin_amdgcn_sched_barrier(0);
 
-    // A fragments [row block][plane]
-    half8 a[2][2];
-    auto read_a = [&](int st) {
-      const int tap = st >> 1, k16 = st & 1;
-      const unsigned char* at = in_tile + (tap / KW) * ROWP + (tap % KW) * PITCH + k16 * 32;
+    // A fragments [row block][plane] of one tap (all 32 channels of the chunk: K = 32 per MFMA)
+    half8 a[4][2];
+    auto read_a = [&](int tap) {
+      const unsigned char* at = in_tile + (tap / KW) * ROWP + (tap % KW) * PITCH;
 #pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) a[mb][pl] = *reinterpret_cast<const half8*>(at + arow[mb] + pl * 64);
     };
@@ -251,19 +246,20 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #endif
     {
 #pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {
+      for (int st = 0; st < NSTEP; ++st) {          // st = 2 * tap + (half of the output channels)
         load_b((st + NB - 1) % NB, step + NB - 1);  // weights of the step NB - 1 ahead
         __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the loads next to their use)
-        read_a(st);
+        if ((st & 1) == 0) read_a(st >> 1);
         // g1s = g1 * 2^-11 is derived here (4 packed fp16 multiplies per fragment) instead of being streamed:
         // a third less weight traffic on the CU's 64 B/clk vector-memory path
         half8 g1s[2];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
           g1s[nb] = __builtin_bit_cast(half8, bq[st % NB][nb * 2]) * (_Float16)(1.0f / 2048.0f);
-#define DMH_TERM(pl, bexpr)                                                                                       \
-  _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = \
-      __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
+#define DMH_TERM(pl, bexpr)                                                                       \
+  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
+      acc[mb][(st & 1) * 2 + nb] =                                                                \
+          __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][(st & 1) * 2 + nb], 0, 0, 0);
         DMH_TERM(1, g1s[nb])                                                 // h2 * g1s   (smallest terms first)
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2 + 1]))      // h1 * g2
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h1 * g1
@@ -284,15 +280,17 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     float* wl = lds + wave * (32 * EP);
     EpilogueRows er(p, b, n0);
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int hb = 0; hb < 2; ++hb) {  // two passes of 32 pixel rows through the wave's slab
       __syncthreads();
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          wl[((r & 3) + 8 * (r >> 2) + 4 * half) * EP + nb * 32 + l31] = acc[mb][nb][r] * inv_s;
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            wl[(m2 * 16 + kg * 4 + r) * EP + nb * 16 + l15] = acc[hb * 2 + m2][nb][r] * inv_s;
       __syncthreads();
-      er.template store_rows<TW>(p, wl, wm * 64 + mb * 32, oy0, ox0);
+      er.template store_rows<TW>(p, wl, wm * 64 + hb * 32, oy0, ox0);
     }
     er.template write_stats_grid<WM, WN, TH>(p, lds, ty, tx);
   }
@@ -318,8 +316,8 @@ __global__ __launch_bounds__(64) void f16x3_wscale_kernel(const float* __restric
   }
 }
 
-// fp16 element index: ((((((nt * nchunks + ch) * NTAPS + tap) * 2 + k16) * 2 + nb) * 2 + plane) * 64 + lane) * 8 + j
-//   -> plane (g1, g2) of w[o = nt*64 + nb*32 + (lane & 31)][c = chunk channel k16*16 + (lane >> 5)*8 + j][tap] * 2^k
+// fp16 element index: ((((((nt * nchunks + ch) * NTAPS + tap) * 2 + nh) * 2 + nb) * 2 + plane) * 64 + lane) * 8 + j
+//   -> plane (g1, g2) of w[o = nt*64 + nh*32 + nb*16 + (lane & 15)][c = chunk channel (lane >> 4)*8 + j][tap] * 2^k
 __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const float* __restrict__ oscale,
                                          _Float16* __restrict__ wp, int Cout, int C0, int C1, int NTAPS, int nch0,
                                          int nch1, int64_t total) {
@@ -334,14 +332,14 @@ __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const floa
   r /= 2;
   const int nb = r % 2;
   r /= 2;
-  const int k16 = r % 2;
+  const int nh = r % 2;
   r /= 2;
   const int tap = r % NTAPS;
   r /= NTAPS;
   const int ch = r % (nch0 + nch1);
   const int nt = r / (nch0 + nch1);
-  const int o = nt * 64 + nb * 32 + (lane & 31);
-  const int k = k16 * 16 + (lane >> 5) * 8 + j;
+  const int o = nt * 64 + nh * 32 + nb * 16 + (lane & 15);
+  const int k = (lane >> 4) * 8 + j;
   int c;
   bool ok;
   if (ch < nch0) {
@@ -407,7 +405,12 @@ static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
 int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   const bool wide = d->Cout % 128 == 0;
   if (d->KH == 1) {
-    return wide ? launch_f16x3<1, 1, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st)
+    static int wide1 = -1;  // development knob
+    if (wide1 < 0) {
+      const char* e = getenv("DMH_F16_WIDE1");
+      wide1 = e ? atoi(e) : 1;
+    }
+    return (wide && wide1) ? launch_f16x3<1, 1, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st)
                 : launch_f16x3<1, 1, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);
   }
   if (d->upsample2) {
