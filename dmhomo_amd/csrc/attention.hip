@@ -278,6 +278,14 @@ extern "C" int dmh_linattn_merge(const float* partial, float* ctx, int B, int n,
   return DMH_OK;
 }
 
+// same merge for partials produced with another split count (linattn_fused.hip)
+extern "C" int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, void* stream) {
+  DMH_REQUIRE(partial && ctx && B > 0 && n > 0 && nsplit > 0, "dmh_linattn_merge_n: bad arguments");
+  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n, nsplit);
+  DMH_CHECK_LAUNCH("dmh_linattn_merge_n");
+  return DMH_OK;
+}
+
 extern "C" int dmh_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int n, float scale,
                                  void* stream) {
   DMH_REQUIRE(qkv && ctx && out && B > 0 && n > 0, "dmh_linattn_apply: bad arguments");

@@ -1,0 +1,562 @@
+// K3f — LinearAttention with its PreNorm LayerNorm and to_qkv projection fused in (CFG:96-103, 246-269):
+// q, k, v are never written to HBM.
+//
+//   pass 1  linattn_kv_kernel     x -> LN -> k, v = W_kv LN(x) (registers) -> per split: max_n k, sum exp, exp(k)^T v
+//   (merge  linattn_merge_kernel  of attention.hip: finishes the softmax over the n pixels, scales by 1/n)
+//   pass 2  linattn_qo_kernel     x -> LN -> q = W_q LN(x) -> softmax over d, * scale -> out = q ctx   [B][n][128]
+//
+// against  LayerNorm (r+w) + to_qkv conv (w 384 channels) + context (r 256) + apply (r 128, w 128):  per 128x128
+// attention of the bench (50 rows) 0.84 GB of HBM traffic instead of 3.6 GB.
+//
+// The projections are f16x3 GEMMs exactly as in conv_f16x3.hip (block-scaled fp16 pieces of the fp32 operands,
+// three v_mfma_f32_16x16x32_f16 per product block, fp32 accumulation; see that file for the error analysis); the
+// staged operand is the LayerNorm output (x - mean) * rstd * g, computed as chan_layernorm_kernel computes it from
+// the per-pixel (mean, rstd) of dmh_pixel_stats.  One wave per head; 64 pixels per sub-tile.
+//   pass 1 multiplies pixels x channels ("pixels as rows"): the accumulator layout (lane = channel, registers =
+//          pixels) is at once the A operand (exp(k - m)) and the B operand (v) of the fp32 16x16x4 MFMA that
+//          contracts over pixels — no lane movement between the two GEMMs;
+//   pass 2 multiplies channels x pixels (q^T): its accumulators (lane = pixel, registers = d) are the B operand of
+//          out^T = ctx^T q^T.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+#define LA_PART (32 + 32 + 1024)  // per (b, split, head): max[32], sum[32], ctx[32][32]  (as attention.hip)
+
+namespace {
+constexpr int KC = 32;      // channels per chunk = K of one MFMA
+constexpr int PITCH = 160;  // LDS bytes per staged pixel (conv_f16x3.hip: conflict-free ds_read_b128)
+constexpr int TP = 64;      // pixels per sub-tile
+constexpr int TILE_BYTES = TP * PITCH;
+
+__device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+
+// Stages one 32-channel chunk of a 64-pixel sub-tile: global x -> LayerNorm -> block scale -> two fp16 planes in LDS,
+// and keeps the running block scale of the sub-tile.  All 256 threads; thread = (pixel tid>>3 (+32), channel quad tid&7).
+struct Stager {
+  const float* xb;     // x of this sample
+  const float* g;      // LayerNorm gain
+  int C, n, p0;
+  int c4, pix0;
+  float mean[2], rstd[2];
+  bool ok[2];
+  float4 v[2];
+  float4 gq;
+  int e_run;
+  int seq = 0;  // staged chunks so far (selects the block-maximum slot; keeps alternating across sub-tiles)
+
+  __device__ __forceinline__ void begin_tile(const float* stats_b, int p0_) {
+    p0 = p0_;
+    e_run = 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pix = p0 + pix0 + 32 * i;
+      ok[i] = pix < n;
+      const int pc = ok[i] ? pix : n - 1;
+      mean[i] = stats_b[(size_t)pc * 2 + 0];
+      rstd[i] = stats_b[(size_t)pc * 2 + 1];
+    }
+  }
+  __device__ __forceinline__ void issue(int ch) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pix = p0 + pix0 + 32 * i;
+      const int pc = pix < n ? pix : n - 1;  // clamped address, masked value
+      v[i] = ld4(xb + (size_t)pc * C + ch * KC + c4 * 4);
+    }
+    gq = ld4(g + ch * KC + c4 * 4);
+  }
+  // returns the factor (<= 1) the accumulators of the sub-tile must be multiplied with (1 when the scale is unchanged)
+  __device__ __forceinline__ float stage(unsigned char* tile, unsigned* mxslot, int ch) {
+    unsigned mx = 0u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 x = v[i];
+      if (ok[i]) {
+        x.x = (x.x - mean[i]) * rstd[i] * gq.x;  // exactly chan_layernorm_kernel's expression
+        x.y = (x.y - mean[i]) * rstd[i] * gq.y;
+        x.z = (x.z - mean[i]) * rstd[i] * gq.z;
+        x.w = (x.w - mean[i]) * rstd[i] * gq.w;
+      } else {
+        x = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      v[i] = x;
+      mx = max(max(mx, absbits(x.x)), max(max(absbits(x.y), absbits(x.z)), absbits(x.w)));
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(&mxslot[seq & 1], mx);
+    __syncthreads();  // block maximum complete; every wave is done reading the previous chunk's tile
+    const unsigned bmx = mxslot[seq & 1];
+    if (threadIdx.x == 0) mxslot[(seq + 1) & 1] = 0u;
+    ++seq;
+    const int e_old = e_run;
+    const int e_ch = min(max((int)(__builtin_amdgcn_readfirstlane(bmx) >> 23), 16), 254);
+    e_run = max(e_run, e_ch);
+    const float sc = __uint_as_float((unsigned)(268 - e_run) << 23);  // largest |x| * sc in [2^14, 2^15)
+    float f = 1.f;
+    if (e_run != e_old && ch > 0) {
+      const int fe = 127 + e_old - e_run;
+      f = fe > 0 ? __uint_as_float((unsigned)fe << 23) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4v xs = float4v{v[i].x, v[i].y, v[i].z, v[i].w} * sc;
+      const half4 h1 = __builtin_convertvector(xs, half4);
+      const float4v rs = (xs - __builtin_convertvector(h1, float4v)) * 2048.f;
+      const half4 h2 = __builtin_convertvector(rs, half4);
+      unsigned char* dst = tile + (pix0 + 32 * i) * PITCH + c4 * 8;
+      *reinterpret_cast<half4*>(dst) = h1;
+      *reinterpret_cast<half4*>(dst + 64) = h2;
+    }
+    __syncthreads();
+    return f;
+  }
+  __device__ __forceinline__ float inv_scale() const { return __uint_as_float((unsigned)(e_run - 14) << 23); }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ pass 1
+// grid = B * nsplit workgroups; workgroup (b, sp) covers `tiles` sub-tiles of 64 pixels; wave = head.
+// wkv: [head 4][chunk][nb 4: k lo, k hi, v lo, v hi][plane 2][lane 64] x 16 B, then 256 floats 2^-k per (head, nb, col)
+__global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ g, const uint4* __restrict__ wkv,
+                                                            const float* __restrict__ oscale, float* __restrict__ partial,
+                                                            int n, int C, int nsplit, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tile = smem;
+  unsigned* mxslot = reinterpret_cast<unsigned*>(smem + TILE_BYTES);
+
+  const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int nch = C / KC;
+
+  Stager st;
+  st.xb = x + (size_t)b * n * C;
+  st.g = g;
+  st.C = C;
+  st.n = n;
+  st.c4 = tid & 7;
+  st.pix0 = tid >> 3;
+  const float* stats_b = stats + (size_t)b * n * 2;
+  if (tid < 2) mxslot[tid] = 0u;
+  __syncthreads();
+
+  const uint4* wb = wkv + (size_t)h * nch * (8 * 64) + lane;
+  float osc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) osc[nb] = oscale[(h * 4 + nb) * 16 + l15];
+
+  // running state over the sub-tiles: per column d = db*16 + l15 (lanes), ctx blocks [db][eb] (rows d, cols e)
+  float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
+  float4v ctx[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ctx[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  if (sp * tiles * TP < n) {
+    st.begin_tile(stats_b, sp * tiles * TP);
+    st.issue(0);
+  }
+  for (int tI = 0; tI < tiles; ++tI) {
+    const int p0 = (sp * tiles + tI) * TP;
+    if (p0 >= n) break;
+    float4v acc[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < nch; ++ch) {
+      uint4 bq[8];  // this chunk's weight fragments travel while the chunk is staged
+#pragma unroll
+      for (int i = 0; i < 8; ++i) bq[i] = wb[(size_t)(ch * 8 + i) * 64];
+      const float f = st.stage(tile, mxslot, ch);
+      if (f != 1.f) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] *= f;
+      }
+      if (ch + 1 < nch) st.issue(ch + 1);
+      half8 a[4][2];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          a[mb][pl] = *reinterpret_cast<const half8*>(tile + (mb * 16 + l15) * PITCH + kg * 16 + pl * 64);
+      half8 g1s[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) g1s[nb] = __builtin_bit_cast(half8, bq[nb * 2]) * (_Float16)(1.0f / 2048.0f);
+#define LA_TERM(pl, bexpr)                                                                          \
+  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) \
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
+      LA_TERM(1, g1s[nb])
+      LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2 + 1]))
+      LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2]))
+#undef LA_TERM
+    }
+    const float inv_s = st.inv_scale();
+    if (tI + 1 < tiles && p0 + TP < n) {  // the next sub-tile's first chunk travels during the softmax / context math
+      st.begin_tile(stats_b, p0 + TP);
+      st.issue(0);
+    }
+
+    // ---- k, v of this sub-tile: acc[mb][nb][r] = value(pixel p0 + mb*16 + 4*kg + r, column nb*16 + l15)
+    float m_new[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = p0 + mb * 16 + 4 * kg + r < n;
+          const float kv = valid ? acc[mb][db][r] * inv_s * osc[db] : -INFINITY;
+          acc[mb][db][r] = kv;
+          m = fmaxf(m, kv);
+        }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      m_new[db] = fmaxf(m_run[db], m);
+    }
+    // rescale the running context rows by exp(m_run - m_new): rows live in (kg, r), the factor in lane l15 = row
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const float fcol = __expf(m_run[db] - m_new[db]);  // 0 on the first sub-tile (m_run = -inf)
+      s_run[db] *= fcol;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float frow = __shfl(fcol, 4 * kg + r);
+        ctx[db][0][r] *= frow;
+        ctx[db][1][r] *= frow;
+      }
+      m_run[db] = m_new[db];
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float s = 0.f;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(acc[mb][db][r] - m_new[db]);  // exp(-inf) = 0 for pixels beyond n
+          acc[mb][db][r] = pv;
+          s += pv;
+        }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      s_run[db] += s;
+    }
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = p0 + mb * 16 + 4 * kg + r < n;
+          acc[mb][2 + eb][r] = valid ? acc[mb][2 + eb][r] * inv_s * osc[2 + eb] : 0.f;
+        }
+    // ctx[d][e] += sum_n p[n][d] v[n][e]: K slot kg of step (mb, r) is pixel mb*16 + 4*kg + r for A and B alike
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int eb = 0; eb < 2; ++eb)
+            ctx[db][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[mb][db][r], acc[mb][2 + eb][r], ctx[db][eb], 0, 0, 0);
+    __syncthreads();  // the LDS tile is free for the next sub-tile
+  }
+
+  float* out = partial + ((size_t)(b * nsplit + sp) * 4 + h) * LA_PART;
+  if (kg == 0) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      out[db * 16 + l15] = m_run[db];
+      out[32 + db * 16 + l15] = s_run[db];
+    }
+  }
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[64 + (db * 16 + 4 * kg + r) * 32 + eb * 16 + l15] = ctx[db][eb][r];
+}
+
+// ------------------------------------------------------------------------------------------ pass 2
+// grid = B * nblk; workgroup covers `tiles` sub-tiles; wave = head.
+// wq: [head 4][chunk][db 2][plane 2][lane 64] x 16 B (row d = db*16 + (lane & 15)); oscale 128 floats per channel h*32+d
+__global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ g, const uint4* __restrict__ wq,
+                                                            const float* __restrict__ oscale, const float* __restrict__ ctxm,
+                                                            float* __restrict__ out, int n, int C, int nblk, int tiles,
+                                                            float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tile = smem;
+  unsigned* mxslot = reinterpret_cast<unsigned*>(smem + TILE_BYTES);
+
+  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int nch = C / KC;
+
+  Stager st;
+  st.xb = x + (size_t)b * n * C;
+  st.g = g;
+  st.C = C;
+  st.n = n;
+  st.c4 = tid & 7;
+  st.pix0 = tid >> 3;
+  const float* stats_b = stats + (size_t)b * n * 2;
+  if (tid < 2) mxslot[tid] = 0u;
+  __syncthreads();
+
+  const uint4* wb = wq + (size_t)h * nch * (4 * 64) + lane;
+  // per-row (d = db*16 + 4*kg + r) weight unscale, and the A operand of out^T = ctx^T q^T:
+  // A[m = e][k slot kg of step (db, r)] = ctx[d = db*16 + 4*kg + r][e = eb*16 + l15]
+  float osc[2][4], ca[2][2][4];
+  const float* cb = ctxm + (size_t)(b * 4 + h) * 1024;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = db * 16 + 4 * kg + r;
+      osc[db][r] = oscale[h * 32 + d];
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) ca[eb][db][r] = cb[d * 32 + eb * 16 + l15];
+    }
+  float* ob = out + (size_t)b * n * 128 + h * 32;
+
+  if (blk * tiles * TP < n) {
+    st.begin_tile(stats_b, blk * tiles * TP);
+    st.issue(0);
+  }
+  for (int tI = 0; tI < tiles; ++tI) {
+    const int p0 = (blk * tiles + tI) * TP;
+    if (p0 >= n) break;
+    float4v acc[2][4];  // q^T: rows d (db, 4*kg + r), columns = pixels (nbn*16 + l15)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int nbn = 0; nbn < 4; ++nbn) acc[db][nbn] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < nch; ++ch) {
+      uint4 aq[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) aq[i] = wb[(size_t)(ch * 4 + i) * 64];
+      const float f = st.stage(tile, mxslot, ch);
+      if (f != 1.f) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int nbn = 0; nbn < 4; ++nbn) acc[db][nbn] *= f;
+      }
+      if (ch + 1 < nch) st.issue(ch + 1);
+      half8 xb[4][2];
+#pragma unroll
+      for (int nbn = 0; nbn < 4; ++nbn)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          xb[nbn][pl] = *reinterpret_cast<const half8*>(tile + (nbn * 16 + l15) * PITCH + kg * 16 + pl * 64);
+      half8 g1s[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) g1s[db] = __builtin_bit_cast(half8, aq[db * 2]) * (_Float16)(1.0f / 2048.0f);
+#define LA_TERM(aexpr, pl)                                                                           \
+  _Pragma("unroll") for (int db = 0; db < 2; ++db) _Pragma("unroll") for (int nbn = 0; nbn < 4; ++nbn) \
+      acc[db][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aexpr, xb[nbn][pl], acc[db][nbn], 0, 0, 0);
+      LA_TERM(g1s[db], 1)
+      LA_TERM(__builtin_bit_cast(half8, aq[db * 2 + 1]), 0)
+      LA_TERM(__builtin_bit_cast(half8, aq[db * 2]), 0)
+#undef LA_TERM
+    }
+    const float inv_s = st.inv_scale();
+    if (tI + 1 < tiles && p0 + TP < n) {
+      st.begin_tile(stats_b, p0 + TP);
+      st.issue(0);
+    }
+
+    // ---- q' = softmax over the 32 d of each pixel column, * scale
+#pragma unroll
+    for (int nbn = 0; nbn < 4; ++nbn) {
+      float m = -INFINITY;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float qv = acc[db][nbn][r] * inv_s * osc[db][r];
+          acc[db][nbn][r] = qv;
+          m = fmaxf(m, qv);
+        }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float s = 0.f;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = expf(acc[db][nbn][r] - m);
+          acc[db][nbn][r] = e;
+          s += e;
+        }
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[db][nbn][r] = (acc[db][nbn][r] / s) * scale;
+    }
+    // ---- out^T[e][n] = sum_d ctx[d][e] q'[n][d]
+#pragma unroll
+    for (int nbn = 0; nbn < 4; ++nbn) {
+      float4v o[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int eb = 0; eb < 2; ++eb)
+            o[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[eb][db][r], acc[db][nbn][r], o[eb], 0, 0, 0);
+      const int pix = p0 + nbn * 16 + l15;  // column = pixel; rows e = eb*16 + 4*kg + r: four consecutive channels
+      if (pix < n) {
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+          st4(ob + (size_t)pix * 128 + eb * 16 + 4 * kg, make_float4(o[eb][0], o[eb][1], o[eb][2], o[eb][3]));
+      }
+    }
+    __syncthreads();  // the LDS tile is free for the next sub-tile
+  }
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+// to_qkv weight [384][C] (1x1, no bias): rows 0..127 q, 128..255 k, 256..383 v, row = part*128 + head*32 + d.
+// per-row scale 2^k with max |w| * 2^k in [2^14, 2^15); oscale = 2^-k
+__global__ __launch_bounds__(64) void linattn_wscale_kernel(const float* __restrict__ w, float* __restrict__ osc_q,
+                                                            float* __restrict__ osc_kv, int C) {
+  const int row = blockIdx.x;  // 0..383
+  float m = 0.f;
+  for (int i = threadIdx.x; i < C; i += 64) m = fmaxf(m, fabsf(w[(size_t)row * C + i]));
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      s = ldexpf(1.f, min(max(e - 15, -100), 100));
+    }
+    if (row < 128) {
+      osc_q[row] = s;
+    } else {
+      // kv order: (head, nb: k lo, k hi, v lo, v hi, col)
+      const int part = row / 128 - 1, hh = (row % 128) / 32, d = row % 32;
+      osc_kv[(hh * 4 + part * 2 + d / 16) * 16 + d % 16] = s;
+    }
+  }
+}
+
+// kv: fp16 index ((((h * nch + ch) * 4 + nb) * 2 + plane) * 64 + lane) * 8 + j ; q: ((((h * nch + ch) * 2 + db) * 2 + plane) * 64 + lane) * 8 + j
+__global__ void linattn_pack_kernel(const float* __restrict__ w, const float* __restrict__ osc_q,
+                                    const float* __restrict__ osc_kv, _Float16* __restrict__ pq,
+                                    _Float16* __restrict__ pkv, int C, int64_t total_q, int64_t total_kv) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nch = C / KC;
+  if (idx < total_q) {
+    int64_t r = idx;
+    const int j = r % 8;
+    r /= 8;
+    const int lane = r % 64;
+    r /= 64;
+    const int plane = r % 2;
+    r /= 2;
+    const int db = r % 2;
+    r /= 2;
+    const int ch = r % nch;
+    const int hh = r / nch;
+    const int row = hh * 32 + db * 16 + (lane & 15);
+    const int c = ch * KC + (lane >> 4) * 8 + j;
+    const float ws = w[(size_t)row * C + c] / osc_q[row];
+    const _Float16 g1 = (_Float16)ws;
+    pq[idx] = plane == 0 ? g1 : (_Float16)(ws - (float)g1);
+  }
+  if (idx < total_kv) {
+    int64_t r = idx;
+    const int j = r % 8;
+    r /= 8;
+    const int lane = r % 64;
+    r /= 64;
+    const int plane = r % 2;
+    r /= 2;
+    const int nb = r % 4;
+    r /= 4;
+    const int ch = r % nch;
+    const int hh = r / nch;
+    const int row = 128 + (nb >> 1) * 128 + hh * 32 + (nb & 1) * 16 + (lane & 15);
+    const int c = ch * KC + (lane >> 4) * 8 + j;
+    const float ws = w[(size_t)row * C + c] / osc_kv[(hh * 4 + nb) * 16 + (lane & 15)];
+    const _Float16 g1 = (_Float16)ws;
+    pkv[idx] = plane == 0 ? g1 : (_Float16)(ws - (float)g1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI
+// packed image (floats): [q fragments: C*128 fp16 * 2 planes][kv fragments: C*256 fp16 * 2 planes][osc_q 128][osc_kv 256]
+extern "C" int64_t dmh_linattn_fused_pack_floats(int C) { return (int64_t)C * 128 + (int64_t)C * 256 + 128 + 256; }
+
+extern "C" int dmh_linattn_fused_pack(const float* w_qkv, float* wpack, int C, void* stream) {
+  DMH_REQUIRE(w_qkv && wpack && C > 0 && C % KC == 0, "dmh_linattn_fused_pack: C must be a multiple of 32 (got %d)", C);
+  hipStream_t s = (hipStream_t)stream;
+  float* osc_q = wpack + (int64_t)C * 384;
+  float* osc_kv = osc_q + 128;
+  hipLaunchKernelGGL(linattn_wscale_kernel, dim3(384), dim3(64), 0, s, w_qkv, osc_q, osc_kv, C);
+  const int64_t total_q = (int64_t)C * 128 * 2, total_kv = (int64_t)C * 256 * 2;
+  hipLaunchKernelGGL(linattn_pack_kernel, dim3((unsigned)cdiv64(total_kv, 256)), dim3(256), 0, s, w_qkv, osc_q, osc_kv,
+                     reinterpret_cast<_Float16*>(wpack), reinterpret_cast<_Float16*>(wpack + (int64_t)C * 128), C,
+                     total_q, total_kv);
+  DMH_CHECK_LAUNCH("dmh_linattn_fused_pack");
+  return DMH_OK;
+}
+
+static int fused_tiles(int B, int n) {
+  // sub-tiles per workgroup: as many as keep >= ~1024 workgroups in flight (at most 8 = 512 pixels)
+  const int nt = cdiv(n, TP);
+  int t = 8;
+  while (t > 1 && (int64_t)B * cdiv(nt, t) < 1024) t >>= 1;
+  return t;
+}
+
+extern "C" int dmh_linattn_fused_splits(int B, int n) { return cdiv(cdiv(n, TP), fused_tiles(B, n)); }
+
+// pass 1: partial[B][splits][4][LA_PART]  (then dmh_linattn_merge with the same split count)
+extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, const float* ln_g, const float* wpack,
+                                         float* partial, int B, int n, int C, void* stream) {
+  DMH_REQUIRE(x && stats && ln_g && wpack && partial, "dmh_linattn_fused_context: null pointer");
+  DMH_REQUIRE(B > 0 && n > 0 && C > 0 && C % KC == 0, "dmh_linattn_fused_context: bad shape (C=%d)", C);
+  const int tiles = fused_tiles(B, n), nsplit = cdiv(cdiv(n, TP), tiles);
+  const uint4* wkv = reinterpret_cast<const uint4*>(wpack + (int64_t)C * 128);
+  const float* osc_kv = wpack + (int64_t)C * 384 + 128;
+  hipLaunchKernelGGL(linattn_kv_kernel, dim3(B * nsplit), dim3(256), TILE_BYTES + 16, (hipStream_t)stream, x, stats, ln_g,
+                     wkv, osc_kv, partial, n, C, nsplit, tiles);
+  DMH_CHECK_LAUNCH("dmh_linattn_fused_context");
+  return DMH_OK;
+}
+
+// pass 2: out[B][n][128]
+extern "C" int dmh_linattn_fused_apply(const float* x, const float* stats, const float* ln_g, const float* wpack,
+                                       const float* ctx, float* out, int B, int n, int C, float scale, void* stream) {
+  DMH_REQUIRE(x && stats && ln_g && wpack && ctx && out, "dmh_linattn_fused_apply: null pointer");
+  DMH_REQUIRE(B > 0 && n > 0 && C > 0 && C % KC == 0, "dmh_linattn_fused_apply: bad shape (C=%d)", C);
+  const int tiles = fused_tiles(B, n), nblk = cdiv(cdiv(n, TP), tiles);
+  const uint4* wq = reinterpret_cast<const uint4*>(wpack);
+  const float* osc_q = wpack + (int64_t)C * 384;
+  hipLaunchKernelGGL(linattn_qo_kernel, dim3(B * nblk), dim3(256), TILE_BYTES + 16, (hipStream_t)stream, x, stats, ln_g, wq,
+                     osc_q, ctx, out, n, C, nblk, tiles, scale);
+  DMH_CHECK_LAUNCH("dmh_linattn_fused_apply");
+  return DMH_OK;
+}

@@ -163,6 +163,70 @@ static int launch_ln(const float* x, const float* g, const float* res, float* ou
   return DMH_OK;
 }
 
+// per-pixel (mean, rstd) of the channel LayerNorm, for consumers that apply it while staging (linattn_fused.hip);
+// same two-pass arithmetic as chan_layernorm_kernel
+template <int LPP, int NV>
+__global__ __launch_bounds__(256) void pixel_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                          int64_t npix, int C, float eps) {
+  const int C4 = C >> 2;
+  const int sub = threadIdx.x % LPP;
+  const int64_t pix_per_block = 256 / LPP;
+  for (int64_t pix = (int64_t)blockIdx.x * pix_per_block + threadIdx.x / LPP; pix < npix;
+       pix += (int64_t)gridDim.x * pix_per_block) {
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < C4) v[j] = ld4(x + pix * C + q * 4);
+      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+#pragma unroll
+    for (int off = LPP >> 1; off; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float qsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      if (q < C4) {
+        const float dx = v[j].x - mean, dy = v[j].y - mean, dz = v[j].z - mean, dw = v[j].w - mean;
+        qsum += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+    }
+#pragma unroll
+    for (int off = LPP >> 1; off; off >>= 1) qsum += __shfl_xor(qsum, off);
+    if (sub == 0) {
+      stats[pix * 2 + 0] = mean;
+      stats[pix * 2 + 1] = 1.0f / sqrtf(qsum / (float)C + eps);
+    }
+  }
+}
+
+template <int LPP, int NV>
+static int launch_ps(const float* x, float* stats, int64_t npix, int C, float eps, hipStream_t st) {
+  const int64_t ppb = 256 / LPP;
+  const int64_t need = cdiv64(npix, ppb);
+  const unsigned grid = (unsigned)(need < 16384 ? need : 16384);
+  hipLaunchKernelGGL((pixel_stats_kernel<LPP, NV>), dim3(grid), dim3(256), 0, st, x, stats, npix, C, eps);
+  DMH_CHECK_LAUNCH("dmh_pixel_stats");
+  return DMH_OK;
+}
+
+extern "C" int dmh_pixel_stats(const float* x, float* stats, int64_t npix, int C, float eps, void* stream) {
+  DMH_REQUIRE(x && stats, "dmh_pixel_stats: null pointer");
+  DMH_REQUIRE(npix > 0 && C > 0 && C % 4 == 0 && C <= 2048, "dmh_pixel_stats: unsupported C=%d", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int C4 = C / 4;
+  if (C4 <= 8) return launch_ps<8, 1>(x, stats, npix, C, eps, st);
+  if (C4 <= 16) return launch_ps<16, 1>(x, stats, npix, C, eps, st);
+  if (C4 <= 32) return launch_ps<32, 1>(x, stats, npix, C, eps, st);
+  if (C4 <= 64) return launch_ps<64, 1>(x, stats, npix, C, eps, st);
+  if (C4 <= 128) return launch_ps<64, 2>(x, stats, npix, C, eps, st);
+  if (C4 <= 256) return launch_ps<64, 4>(x, stats, npix, C, eps, st);
+  return launch_ps<64, 8>(x, stats, npix, C, eps, st);
+}
+
 extern "C" int dmh_chan_layernorm(const float* x, const float* g, const float* res, float* out, int64_t npix, int C,
                                   float eps, void* stream) {
   DMH_REQUIRE(x && g && out, "dmh_chan_layernorm: null pointer");

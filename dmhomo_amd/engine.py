@@ -15,6 +15,7 @@ layout of ``dmh_conv2d`` and transposes the small linears — once per weight ve
   Upsample     nearest x2 is index math inside the 3x3 gather
 """
 import math
+import os
 
 import torch
 
@@ -22,6 +23,7 @@ from . import ops
 
 HEADS, DIM_HEAD = 4, 32     # CFG:246,275
 ATTN_SCALE = DIM_HEAD ** -0.5
+FUSED_LINATTN = os.environ.get('DMH_FUSED_LINATTN', '1') != '0'   # development knob: '0' = separate LayerNorm / to_qkv / core
 
 
 class _Res:
@@ -29,7 +31,7 @@ class _Res:
 
 
 class _Attn:
-    __slots__ = ('linear', 'ln_g', 'qkv', 'out', 'out_g')
+    __slots__ = ('linear', 'ln_g', 'qkv', 'pla', 'out', 'out_g')
 
 
 def _ceil4(c):
@@ -113,7 +115,13 @@ class UnetEngine:
             a = _Attn()
             a.linear = linear
             a.ln_g = f32(prefix + '.fn.norm.g').reshape(-1).contiguous()
-            a.qkv = conv(prefix + '.fn.fn.to_qkv', c, bias=False)
+            a.pla = None
+            if linear and c % 32 == 0 and FUSED_LINATTN:
+                # LayerNorm + to_qkv + both attention passes in two kernels (ops.linear_attention_fused)
+                a.qkv = None
+                a.pla = ops.PackedLinAttn(f32(prefix + '.fn.fn.to_qkv.weight'))
+            else:
+                a.qkv = conv(prefix + '.fn.fn.to_qkv', c, bias=False)
             if linear:
                 a.out = conv(prefix + '.fn.fn.to_out.0', HEADS * DIM_HEAD)
                 a.out_g = f32(prefix + '.fn.fn.to_out.1.g').reshape(-1).contiguous()
@@ -183,6 +191,10 @@ class UnetEngine:
         return ops.gn_silu_residual(y2, coef2, x0)
 
     def _attn(self, a, x):
+        if a.pla is not None:
+            o = ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE)
+            y = ops.conv2d(a.out, o)
+            return ops.chan_layernorm(y, a.out_g, res=x)
         xn = ops.chan_layernorm(x, a.ln_g)
         qkv = ops.conv2d(a.qkv, xn)
         if a.linear:

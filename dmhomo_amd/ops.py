@@ -127,6 +127,37 @@ def linear_attention_core(qkv, scale):
     return out
 
 
+class PackedLinAttn:
+    """to_qkv weight of a LinearAttention (384, C, 1, 1) packed for the fused kernels (once per weight version)."""
+
+    def __init__(self, w_qkv):
+        c = w_qkv.shape[1]
+        assert w_qkv.shape[0] == 384 and c % 32 == 0, w_qkv.shape
+        w = w_qkv.detach().reshape(384, c).contiguous().float()
+        self.c = c
+        self.wpack = _empty((lib().dmh_linattn_fused_pack_floats(c),), w)
+        call('dmh_linattn_fused_pack', ptr(w), ptr(self.wpack), c)
+
+
+def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5):
+    """K3f.  x (B,H,W,C) -> attention core output (B,H,W,128) of LinearAttention(PreNorm-LayerNorm(x)): LayerNorm,
+    to_qkv and both attention passes in two kernels, q/k/v never stored."""
+    B, H, W, c = x.shape
+    assert c == pla.c
+    n = H * W
+    stats = _empty((B, n, 2), x)
+    call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, c, float(eps))
+    ns = lib().dmh_linattn_fused_splits(B, n)
+    partial = _empty((B, ns, 4, 1088), x)
+    ctx = _empty((B, 4, 32, 32), x)
+    out = _empty((B, H, W, 128), x)
+    call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c)
+    call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
+    call('dmh_linattn_fused_apply', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(out), B, n, c,
+         float(scale))
+    return out
+
+
 def attention_core(qkv, scale):
     """K4.  qkv (B,H,W,384) -> (B,H,W,128)."""
     B, H, W, c = qkv.shape

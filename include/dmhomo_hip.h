@@ -113,6 +113,23 @@ int dmh_linattn_merge(const float* partial, float* ctx, int B, int n, void* stre
 /* pass 2: out[b][p][h*32+e] = sum_d ctx[d][e] * (softmax_d(q[p]) * scale)[d]; out NHWC [B][n][128] */
 int dmh_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int n, float scale, void* stream);
 
+/* Fused LinearAttention (PreNorm LayerNorm + to_qkv + attention core, CFG:96-103,246-269): q, k, v stay on chip.
+ *   stats  = dmh_pixel_stats(x)                         per-pixel (mean, rstd) of the PreNorm LayerNorm, [npix][2]
+ *   wpack  = dmh_linattn_fused_pack(to_qkv.weight)      once per weight version; dmh_linattn_fused_pack_floats(C) floats
+ *   dmh_linattn_fused_context -> partial[B][dmh_linattn_fused_splits(B,n)][4][1088]
+ *   dmh_linattn_merge_n       -> ctx[B][4][32][32]
+ *   dmh_linattn_fused_apply   -> out[B][n][128]         (then to_out conv + LayerNorm + residual as before)
+ * x: NHWC [B][n][C], C a multiple of 32. */
+int dmh_pixel_stats(const float* x, float* stats, int64_t npix, int C, float eps, void* stream);
+int64_t dmh_linattn_fused_pack_floats(int C);
+int dmh_linattn_fused_pack(const float* w_qkv, float* wpack, int C, void* stream);
+int dmh_linattn_fused_splits(int B, int n);
+int dmh_linattn_fused_context(const float* x, const float* stats, const float* ln_g, const float* wpack,
+                              float* partial, int B, int n, int C, void* stream);
+int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, void* stream);
+int dmh_linattn_fused_apply(const float* x, const float* stats, const float* ln_g, const float* wpack,
+                            const float* ctx, float* out, int B, int n, int C, float scale, void* stream);
+
 /* K4  Attention core, CFG:287-295: softmax_j((q*scale)^T k) v; out NHWC [B][n][128] */
 int dmh_attention(const float* qkv, float* out, int B, int n, float scale, void* stream);
 

@@ -198,6 +198,33 @@ def test_linear_attention_core(ops, H, W):
     close(f'linattn {H}x{W}', nchw(ops.linear_attention_core(nhwc(qkv), 32 ** -0.5)), ref, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize('C,H,W', [(64, 16, 16), (64, 7, 9), (128, 24, 40), (256, 8, 8), (64, 40, 56)])
+def test_linear_attention_fused(ops, C, H, W):
+    """PreNorm LayerNorm + to_qkv + LinearAttention core in two kernels (q, k, v never stored) against the unfused
+    math in fp64: ragged pixel counts (sub-tiles of 64 pixels, several per workgroup), all channel widths of the UNet"""
+    B = 3
+    x = rand((B, C, H, W), 40) * 1.7 + 0.3
+    x[:, :C // 2] *= 4.0                                   # two channel chunks with different block maxima
+    g = 1 + 0.2 * rand((C,), 41)
+    w = rand((384, C, 1, 1), 42, C ** -0.5)
+    xd = x.double()
+    mean = xd.mean(1, keepdim=True)
+    var = xd.var(1, unbiased=False, keepdim=True)
+    xn = (xd - mean) / (var + 1e-5).sqrt() * g.double()[None, :, None, None]
+    qkv = F.conv2d(xn, w.double())
+    n = H * W
+    q, k, v = [t.reshape(B, 4, 32, n) for t in qkv.chunk(3, dim=1)]
+    q = q.softmax(dim=-2) * 32 ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum('b h d n, b h e n -> b h d e', k, v / n)
+    ref = torch.einsum('b h d e, b h d n -> b h e n', ctx, q).reshape(B, 128, H, W)
+    pla = ops.PackedLinAttn(w.to(dev()))
+    got = nchw(ops.linear_attention_fused(nhwc(x), g.to(dev()), pla, 32 ** -0.5)).double()
+    rel = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f'[parity] linattn fused C={C} {H}x{W}: rel_to_max={rel:.3e} ref_absmax={ref.abs().max().item():.3e}')
+    assert torch.isfinite(got).all() and rel < 2e-5, rel
+
+
 def test_linear_attention_uniform_k_gives_mean_v(ops):
     """known answer: constant k -> softmax_n uniform -> ctx[d][e] = mean_n(v[e]) / n for every d (v is scaled by 1/n)"""
     H = W = 12
