@@ -9,7 +9,8 @@ layout of ``dmh_conv2d`` and transposes the small linears — once per weight ve
   ResnetBlock  = conv3x3(+GN stats) -> gn_finalize(scale/shift) -> conv3x3 with fused
                  GN+SiLU prologue (+stats) -> gn_finalize -> SiLU(GN)+residual (fused into the
                  1x1 res_conv epilogue when the block changes width)
-  LinearAttn   = channel-LN -> 1x1 qkv -> context / merge / apply -> 1x1 out -> channel-LN + x
+  LinearAttn   = pixel stats -> fused LN + to_qkv + context -> merge -> fused LN + to_q + apply -> 1x1 out ->
+                 channel-LN + x   (q, k, v never stored; unfused fallback when C % 32 != 0)
   Attention    = channel-LN -> 1x1 qkv -> flash core -> 1x1 out (+x in the epilogue)
   torch.cat    never materialises: convs take two source pointers
   Upsample     nearest x2 is index math inside the 3x3 gather
