@@ -55,6 +55,10 @@ SIGNATURES = {
     'dmh_linattn_fused_pack': (c_int, [c_f32p, c_f32p, c_int, C.c_void_p]),
     'dmh_linattn_fused_splits': (c_int, [c_int, c_int]),
     'dmh_linattn_fused_context': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_linattn_out_pack_floats': (c_i64, []),
+    'dmh_linattn_out_pack': (c_int, [c_f32p, c_f32p, C.c_void_p]),
+    'dmh_linattn_fused_apply_out': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
+                                            c_int, c_int, c_float, c_float, C.c_void_p]),
     'dmh_linattn_merge_n': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
     'dmh_linattn_fused_apply': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float,
                                         C.c_void_p]),

@@ -294,14 +294,31 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------ pass 2
 // grid = B * nblk; workgroup covers `tiles` sub-tiles; wave = head.
 // wq: [head 4][chunk][db 2][plane 2][lane 64] x 16 B (row d = db*16 + (lane & 15)); oscale 128 floats per channel h*32+d
+//
+// FUSE (C == 64): the rest of the block too — y = to_out(out) + bias (an f16x3 GEMM over the 32 channels of the head,
+// the out^T accumulators being its B operand; the four heads' partial sums meet in LDS), LayerNorm over the 64
+// channels, + x — so neither `out` nor the to_out result ever reaches HBM: CFG:254-256 (to_out), :103 (Residual).
+struct FuseOut {
+  const uint4* wo;      // [head 4][c block 4][plane 2][lane 64] x 16 B: to_out weight, K slot (kg, j) = e (j<4 ? 4kg+j : 16+4kg+j-4)
+  const float* osc_o;   // 64: 2^-k of the to_out rows
+  const float* bias;    // 64
+  const float* g_out;   // 64: gain of the LayerNorm after to_out
+  float* y;             // [B][n][64]
+  float eps;
+};
+constexpr int YP = 68;                                  // pitch (floats) of a pixel's 64 channels in the exchange buffer
+constexpr int YX_BYTES = 4 * TP * YP * 4;               // [head][pixel][channel] partial sums: 69632 B
+
+template <bool FUSE>
 __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const uint4* __restrict__ wq,
                                                             const float* __restrict__ oscale, const float* __restrict__ ctxm,
                                                             float* __restrict__ out, int n, int C, int nblk, int tiles,
-                                                            float scale) {
+                                                            float scale, FuseOut fo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* tile = smem;
   unsigned* mxslot = reinterpret_cast<unsigned*>(smem + TILE_BYTES);
+  float* yx = reinterpret_cast<float*>(smem + TILE_BYTES + 16);  // FUSE only
 
   const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -334,6 +351,16 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       for (int eb = 0; eb < 2; ++eb) ca[eb][db][r] = cb[d * 32 + eb * 16 + l15];
     }
   float* ob = out + (size_t)b * n * 128 + h * 32;
+  // FUSE: to_out weight fragments of this head (A operand: rows c, K = the head's 32 channels), kept in registers
+  half8 wo1[4], wo2[4], wo1s[4];
+  if (FUSE) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      wo1[cb] = __builtin_bit_cast(half8, fo.wo[((h * 4 + cb) * 2 + 0) * 64 + lane]);
+      wo2[cb] = __builtin_bit_cast(half8, fo.wo[((h * 4 + cb) * 2 + 1) * 64 + lane]);
+      wo1s[cb] = wo1[cb] * (_Float16)(1.0f / 2048.0f);
+    }
+  }
 
   if (blk * tiles * TP < n) {
     st.begin_tile(stats_b, blk * tiles * TP);
@@ -414,6 +441,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) acc[db][nbn][r] = (acc[db][nbn][r] / s) * scale;
     }
     // ---- out^T[e][n] = sum_d ctx[d][e] q'[n][d]
+    float4v yacc[4][4];  // FUSE: this head's part of to_out: rows c (cb, 4*kg + r), columns = pixels
 #pragma unroll
     for (int nbn = 0; nbn < 4; ++nbn) {
       float4v o[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
@@ -424,11 +452,88 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
 #pragma unroll
           for (int eb = 0; eb < 2; ++eb)
             o[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[eb][db][r], acc[db][nbn][r], o[eb], 0, 0, 0);
-      const int pix = p0 + nbn * 16 + l15;  // column = pixel; rows e = eb*16 + 4*kg + r: four consecutive channels
-      if (pix < n) {
+      if (!FUSE) {
+        const int pix = p0 + nbn * 16 + l15;  // column = pixel; rows e = eb*16 + 4*kg + r: four consecutive channels
+        if (pix < n) {
+#pragma unroll
+          for (int eb = 0; eb < 2; ++eb)
+            st4(ob + (size_t)pix * 128 + eb * 16 + 4 * kg, make_float4(o[eb][0], o[eb][1], o[eb][2], o[eb][3]));
+        }
+      } else {
+        // the 8 values of this lane (e = eb*16 + 4*kg + r of pixel column l15) are one K = 32 B-fragment slice;
+        // block scale per pixel column (max over the column's 32 e = over the 4 kg lanes), fp16 pieces as everywhere
+        unsigned mx = 0u;
 #pragma unroll
         for (int eb = 0; eb < 2; ++eb)
-          st4(ob + (size_t)pix * 128 + eb * 16 + 4 * kg, make_float4(o[eb][0], o[eb][1], o[eb][2], o[eb][3]));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = max(mx, absbits(o[eb][r]));
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, 16));
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, 32));
+        const int ex = min(max((int)(mx >> 23), 16), 254);
+        const float sc = __uint_as_float((unsigned)(268 - ex) << 23), inv = __uint_as_float((unsigned)(ex - 14) << 23);
+        half8 h1, h2;
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float xs = o[eb][r] * sc;
+            const _Float16 a1 = (_Float16)xs;
+            h1[eb * 4 + r] = a1;
+            h2[eb * 4 + r] = (_Float16)((xs - (float)a1) * 2048.f);
+          }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          float4v t = float4v{0.f, 0.f, 0.f, 0.f};
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1s[cb], h2, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo2[cb], h1, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h1, t, 0, 0, 0);
+          yacc[cb][nbn] = t * inv;
+        }
+      }
+    }
+    if (FUSE) {
+      // partial sums of the four heads -> LDS [head][pixel][channel]; lane (pixel column l15 of block nbn) holds the four
+      // consecutive channels cb*16 + 4*kg .. +3
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int nbn = 0; nbn < 4; ++nbn)
+          st4(yx + ((h * TP) + nbn * 16 + l15) * YP + cb * 16 + 4 * kg,
+              make_float4(yacc[cb][nbn][0], yacc[cb][nbn][1], yacc[cb][nbn][2], yacc[cb][nbn][3]));
+      __syncthreads();
+      // 64 pixels x 16 channel quads: sum the heads, undo the weight scale, + bias, LayerNorm over the 64 channels (two
+      // passes, as chan_layernorm_kernel), * g, + x
+      const int quad = tid & 15;
+      const float4 oq = ld4(fo.osc_o + quad * 4), bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pl = (tid >> 4) + 16 * i;  // pixel of the sub-tile
+        const float* yp = yx + pl * YP + quad * 4;
+        const float4 y0 = ld4(yp), y1 = ld4(yp + TP * YP), y2 = ld4(yp + 2 * TP * YP), y3 = ld4(yp + 3 * TP * YP);
+        float4 v;
+        v.x = fmaf((y0.x + y1.x) + (y2.x + y3.x), oq.x, bq4.x);
+        v.y = fmaf((y0.y + y1.y) + (y2.y + y3.y), oq.y, bq4.y);
+        v.z = fmaf((y0.z + y1.z) + (y2.z + y3.z), oq.z, bq4.z);
+        v.w = fmaf((y0.w + y1.w) + (y2.w + y3.w), oq.w, bq4.w);
+        float sm = (v.x + v.y) + (v.z + v.w);
+#pragma unroll
+        for (int off = 8; off; off >>= 1) sm += __shfl_xor(sm, off);
+        const float mean = sm / 64.f;
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        float qs = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+        for (int off = 8; off; off >>= 1) qs += __shfl_xor(qs, off);
+        const float rs = 1.0f / sqrtf(qs / 64.f + fo.eps);
+        const int pix = p0 + pl;
+        if (pix < n) {
+          const float4 xr = ld4(st.xb + (size_t)pix * 64 + quad * 4);
+          float4 r4;
+          r4.x = dx * rs * gq4.x + xr.x;
+          r4.y = dy * rs * gq4.y + xr.y;
+          r4.z = dz * rs * gq4.z + xr.z;
+          r4.w = dw * rs * gq4.w + xr.w;
+          st4(fo.y + ((size_t)b * n + pix) * 64 + quad * 4, r4);
+        }
       }
     }
     __syncthreads();  // the LDS tile is free for the next sub-tile
@@ -555,8 +660,89 @@ extern "C" int dmh_linattn_fused_apply(const float* x, const float* stats, const
   const int tiles = fused_tiles(B, n), nblk = cdiv(cdiv(n, TP), tiles);
   const uint4* wq = reinterpret_cast<const uint4*>(wpack);
   const float* osc_q = wpack + (int64_t)C * 384;
-  hipLaunchKernelGGL(linattn_qo_kernel, dim3(B * nblk), dim3(256), TILE_BYTES + 16, (hipStream_t)stream, x, stats, ln_g, wq,
-                     osc_q, ctx, out, n, C, nblk, tiles, scale);
+  FuseOut fo = {};
+  hipLaunchKernelGGL(linattn_qo_kernel<false>, dim3(B * nblk), dim3(256), TILE_BYTES + 16, (hipStream_t)stream, x, stats,
+                     ln_g, wq, osc_q, ctx, out, n, C, nblk, tiles, scale, fo);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_apply");
+  return DMH_OK;
+}
+
+// ---- to_out weight [64][128] (1x1) for the fully fused pass 2 (C == 64)
+// fp16 index (((h * 4 + cb) * 2 + plane) * 64 + lane) * 8 + j  ->  piece of w[c = cb*16 + (lane & 15)][h*32 + e],
+// e = j < 4 ? 4*kg + j : 16 + 4*kg + (j - 4), kg = lane >> 4; then 64 floats 2^-k per row c
+__global__ __launch_bounds__(64) void linattn_wo_scale_kernel(const float* __restrict__ w, float* __restrict__ osc) {
+  const int c = blockIdx.x;
+  float m = fmaxf(fabsf(w[c * 128 + threadIdx.x]), fabsf(w[c * 128 + 64 + threadIdx.x]));
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      s = ldexpf(1.f, min(max(e - 15, -100), 100));
+    }
+    osc[c] = s;
+  }
+}
+__global__ void linattn_wo_pack_kernel(const float* __restrict__ w, const float* __restrict__ osc,
+                                       _Float16* __restrict__ wp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // 4*4*2*64*8 = 16384
+  if (idx >= 16384) return;
+  int r = idx;
+  const int j = r % 8;
+  r /= 8;
+  const int lane = r % 64;
+  r /= 64;
+  const int plane = r % 2;
+  r /= 2;
+  const int cb = r % 4;
+  const int hh = r / 4;
+  const int c = cb * 16 + (lane & 15), kg = lane >> 4;
+  const int e = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
+  const float ws = w[c * 128 + hh * 32 + e] / osc[c];
+  const _Float16 g1 = (_Float16)ws;
+  wp[idx] = plane == 0 ? g1 : (_Float16)(ws - (float)g1);
+}
+
+extern "C" int64_t dmh_linattn_out_pack_floats(void) { return 16384 / 2 + 64; }
+
+extern "C" int dmh_linattn_out_pack(const float* w_out, float* wpack, void* stream) {
+  DMH_REQUIRE(w_out && wpack, "dmh_linattn_out_pack: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(linattn_wo_scale_kernel, dim3(64), dim3(64), 0, s, w_out, wpack + 8192);
+  hipLaunchKernelGGL(linattn_wo_pack_kernel, dim3(64), dim3(256), 0, s, w_out, wpack + 8192,
+                     reinterpret_cast<_Float16*>(wpack));
+  DMH_CHECK_LAUNCH("dmh_linattn_out_pack");
+  return DMH_OK;
+}
+
+// pass 2 with to_out + bias, LayerNorm, + x fused in (C == 64): y[B][n][64] = x + LN(to_out(attention(LN(x))))
+extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, const float* ln_g, const float* wpack,
+                                           const float* ctx, const float* wopack, const float* out_bias,
+                                           const float* out_ln_g, float* y, int B, int n, int C, float scale,
+                                           float eps, void* stream) {
+  DMH_REQUIRE(x && stats && ln_g && wpack && ctx && wopack && out_bias && out_ln_g && y,
+              "dmh_linattn_fused_apply_out: null pointer");
+  DMH_REQUIRE(B > 0 && n > 0 && C == 64, "dmh_linattn_fused_apply_out: only C == 64 (got %d)", C);
+  const int tiles = fused_tiles(B, n), nblk = cdiv(cdiv(n, TP), tiles);
+  const uint4* wq = reinterpret_cast<const uint4*>(wpack);
+  const float* osc_q = wpack + (int64_t)C * 384;
+  FuseOut fo;
+  fo.wo = reinterpret_cast<const uint4*>(wopack);
+  fo.osc_o = wopack + 8192;
+  fo.bias = out_bias;
+  fo.g_out = out_ln_g;
+  fo.y = y;
+  fo.eps = eps;
+  constexpr int LDS = TILE_BYTES + 16 + YX_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)linattn_qo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    DMH_REQUIRE(e == hipSuccess, "dmh_linattn_fused_apply_out: cannot raise the LDS limit");
+    attr = true;
+  }
+  hipLaunchKernelGGL(linattn_qo_kernel<true>, dim3(B * nblk), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wq,
+                     osc_q, ctx, nullptr, n, C, nblk, tiles, scale, fo);
+  DMH_CHECK_LAUNCH("dmh_linattn_fused_apply_out");
   return DMH_OK;
 }

@@ -32,7 +32,7 @@ class _Res:
 
 
 class _Attn:
-    __slots__ = ('linear', 'ln_g', 'qkv', 'pla', 'out', 'out_g')
+    __slots__ = ('linear', 'ln_g', 'qkv', 'pla', 'plo', 'out', 'out_g')
 
 
 def _ceil4(c):
@@ -123,9 +123,13 @@ class UnetEngine:
                 a.pla = ops.PackedLinAttn(f32(prefix + '.fn.fn.to_qkv.weight'))
             else:
                 a.qkv = conv(prefix + '.fn.fn.to_qkv', c, bias=False)
+            a.plo = None
             if linear:
                 a.out = conv(prefix + '.fn.fn.to_out.0', HEADS * DIM_HEAD)
                 a.out_g = f32(prefix + '.fn.fn.to_out.1.g').reshape(-1).contiguous()
+                if a.pla is not None and c == 64:   # to_out + LayerNorm + residual ride in the second fused pass
+                    a.plo = ops.PackedLinAttnOut(f32(prefix + '.fn.fn.to_out.0.weight'),
+                                                 f32(prefix + '.fn.fn.to_out.0.bias'), a.out_g)
             else:
                 a.out = conv(prefix + '.fn.fn.to_out', HEADS * DIM_HEAD)
                 a.out_g = None
@@ -192,6 +196,8 @@ class UnetEngine:
         return ops.gn_silu_residual(y2, coef2, x0)
 
     def _attn(self, a, x):
+        if a.plo is not None:
+            return ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, out=a.plo)
         if a.pla is not None:
             o = ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE)
             y = ops.conv2d(a.out, o)

@@ -139,9 +139,24 @@ class PackedLinAttn:
         call('dmh_linattn_fused_pack', ptr(w), ptr(self.wpack), c)
 
 
-def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5):
+class PackedLinAttnOut:
+    """to_out of a LinearAttention with dim 64: conv weight (64, 128, 1, 1) + bias + the gain of its LayerNorm, packed for
+    the fully fused second pass."""
+
+    def __init__(self, w_out, bias, ln_g):
+        assert tuple(w_out.shape[:2]) == (64, 128), w_out.shape
+        w = w_out.detach().reshape(64, 128).contiguous().float()
+        self.wpack = _empty((lib().dmh_linattn_out_pack_floats(),), w)
+        call('dmh_linattn_out_pack', ptr(w), ptr(self.wpack))
+        self.bias = bias.detach().contiguous().float()
+        self.ln_g = ln_g.detach().reshape(-1).contiguous().float()
+
+
+def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None):
     """K3f.  x (B,H,W,C) -> attention core output (B,H,W,128) of LinearAttention(PreNorm-LayerNorm(x)): LayerNorm,
-    to_qkv and both attention passes in two kernels, q/k/v never stored."""
+    to_qkv and both attention passes in two kernels, q/k/v never stored.
+    With ``out`` (PackedLinAttnOut, C == 64) the second pass also applies to_out, its LayerNorm and the residual:
+    returns x + LN(to_out(core)) of shape (B,H,W,64) — the whole Residual(PreNorm(LinearAttention)) block."""
     B, H, W, c = x.shape
     assert c == pla.c
     n = H * W
@@ -150,12 +165,17 @@ def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5):
     ns = lib().dmh_linattn_fused_splits(B, n)
     partial = _empty((B, ns, 4, 1088), x)
     ctx = _empty((B, 4, 32, 32), x)
-    out = _empty((B, H, W, 128), x)
     call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c)
     call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
-    call('dmh_linattn_fused_apply', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(out), B, n, c,
+    if out is not None:
+        y = _empty((B, H, W, 64), x)
+        call('dmh_linattn_fused_apply_out', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(out.wpack),
+             ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps))
+        return y
+    o = _empty((B, H, W, 128), x)
+    call('dmh_linattn_fused_apply', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(o), B, n, c,
          float(scale))
-    return out
+    return o
 
 
 def attention_core(qkv, scale):

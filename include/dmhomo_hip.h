@@ -129,6 +129,14 @@ int dmh_linattn_fused_context(const float* x, const float* stats, const float* l
 int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, void* stream);
 int dmh_linattn_fused_apply(const float* x, const float* stats, const float* ln_g, const float* wpack,
                             const float* ctx, float* out, int B, int n, int C, float scale, void* stream);
+/* C == 64: pass 2 carries the rest of the block too — y[B][n][64] = x + LayerNorm(to_out(attention) + bias) * g
+ * (CFG:254-256, 103): the to_out weight [64][128] is packed once by dmh_linattn_out_pack
+ * (dmh_linattn_out_pack_floats() floats). */
+int64_t dmh_linattn_out_pack_floats(void);
+int dmh_linattn_out_pack(const float* w_out, float* wpack, void* stream);
+int dmh_linattn_fused_apply_out(const float* x, const float* stats, const float* ln_g, const float* wpack,
+                                const float* ctx, const float* wopack, const float* out_bias, const float* out_ln_g,
+                                float* y, int B, int n, int C, float scale, float eps, void* stream);
 
 /* K4  Attention core, CFG:287-295: softmax_j((q*scale)^T k) v; out NHWC [B][n][128] */
 int dmh_attention(const float* qkv, float* out, int B, int n, float scale, void* stream);

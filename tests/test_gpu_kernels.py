@@ -225,6 +225,39 @@ def test_linear_attention_fused(ops, C, H, W):
     assert torch.isfinite(got).all() and rel < 2e-5, rel
 
 
+@pytest.mark.parametrize('H,W', [(16, 16), (7, 9), (40, 56)])
+def test_linear_attention_block_fused(ops, H, W):
+    """dim 64: the whole Residual(PreNorm(LinearAttention)) block — LN, to_qkv, attention, to_out + bias, LN, + x — in the
+    two fused passes, against fp64"""
+    B, C = 3, 64
+    x = rand((B, C, H, W), 50) * 1.3 + 0.2
+    g = 1 + 0.2 * rand((C,), 51)
+    w = rand((384, C, 1, 1), 52, C ** -0.5)
+    wo = rand((C, 128, 1, 1), 53, 128 ** -0.5) * 30.0          # the core output is O(1e-3): make to_out's result O(1)
+    bo = rand((C,), 54, 0.1)
+    go = 1 + 0.2 * rand((C,), 55)
+
+    def ln(t, gain):
+        m = t.mean(1, keepdim=True)
+        v = t.var(1, unbiased=False, keepdim=True)
+        return (t - m) / (v + 1e-5).sqrt() * gain.double()[None, :, None, None]
+    xd = x.double()
+    qkv = F.conv2d(ln(xd, g), w.double())
+    n = H * W
+    q, k, v = [t.reshape(B, 4, 32, n) for t in qkv.chunk(3, dim=1)]
+    q = q.softmax(dim=-2) * 32 ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum('b h d n, b h e n -> b h d e', k, v / n)
+    core = torch.einsum('b h d e, b h d n -> b h e n', ctx, q).reshape(B, 128, H, W)
+    ref = xd + ln(F.conv2d(core, wo.double(), bo.double()), go)
+    pla = ops.PackedLinAttn(w.to(dev()))
+    plo = ops.PackedLinAttnOut(wo.to(dev()), bo.to(dev()), go.to(dev()))
+    got = nchw(ops.linear_attention_fused(nhwc(x), g.to(dev()), pla, 32 ** -0.5, out=plo)).double()
+    rel = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f'[parity] linattn block fused {H}x{W}: rel_to_max={rel:.3e} ref_absmax={ref.abs().max().item():.3e}')
+    assert torch.isfinite(got).all() and rel < 2e-5, rel
+
+
 def test_linear_attention_uniform_k_gives_mean_v(ops):
     """known answer: constant k -> softmax_n uniform -> ctx[d][e] = mean_n(v[e]) / n for every d (v is scaled by 1/n)"""
     H = W = 12
