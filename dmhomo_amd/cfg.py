@@ -281,6 +281,14 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         rgb_flow = ops.affine(rgb_flow.to(torch.float32), 2., -1.)      # normalize_to_neg_one_to_one, CFG:716
         return self.ddim_sample(classes, rgb_flow, flow, mask, shape, cond_scale)
 
+    @torch.no_grad()
+    def interpolate(self, x1, x2, t=None, lam=0.5):
+        """CFG:722-736 calls ``self.p_sample(img, t)`` — two arguments for a method that needs classes and conditions
+        (CFG:639-654), and p_sample itself mis-calls p_mean_variance: it raises TypeError in the
+        reference for any t > 0, and so does this."""
+        raise TypeError('classifier_free_guidance.GaussianDiffusion.interpolate is not callable in the reference '
+                        '(CFG:733 vs CFG:639); use denoising_diffusion_pytorch.GaussianDiffusion.interpolate')
+
     def q_sample(self, x_start, t, noise=None):
         """CFG:738-742."""
         noise = default(noise, lambda: self.rng.randn(x_start.shape, x_start.device))

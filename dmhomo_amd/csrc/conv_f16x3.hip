@@ -101,6 +101,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   const int Wlim = UPS ? p.Win * 2 : p.Win;
 
   if (tid < 2) mxslot[tid] = 0u;
+#ifdef DMH_STAMPS
+  // diagnostic build only (make stamps; tools/f16_stamps.py): per-wave cycle totals of each phase over this tile's stats slot
+  unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev, t_now;
+#define STAMP(i)                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  tk[i] += t_now - t_prev;                                                       \
+  t_prev = t_now;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+  const unsigned long long t_begin = t_prev;
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();  // constant 100 MHz
+#else
+#define STAMP(i)
+#endif
 
   // LDS byte offset of this lane's A rows at tap (0,0), plane 0: four 16-pixel row blocks per wave
   static_assert(TW == 16, "a 16-row MFMA block is one tile row");
@@ -195,7 +211,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #pragma unroll
     for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
     if (lane == 0) atomicMax(&mxslot[ch & 1], mx);
+    STAMP(0)  // wait for the halo loads + prologue + block maximum
     __syncthreads();  // block maximum complete; every wave is done reading the previous chunk's tile
+    STAMP(1)  // barrier 1
     const unsigned bmx = mxslot[ch & 1];
     if (tid == 0) mxslot[(ch + 1) & 1] = 0u;
     // ---- block scale: running maximum over the chunks, so the scale only ever shrinks (no overflow on rescale)
@@ -227,7 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
         *reinterpret_cast<half4*>(dst + 64) = h2;
       }
     }
+    STAMP(2)  // rescale + split + LDS write
     __syncthreads();
+    STAMP(3)  // barrier 2
     // the next chunk's tile travels during this chunk's matrix phase (last chunk: harmless re-load of itself)
     issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
     __builtin_amdgcn_sched_barrier(0);
@@ -268,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(4)  // matrix phase
   }
 
   // ---- epilogue: accumulators / block scale -> LDS transpose -> rows (conv_args.h applies 2^-k per channel)
@@ -292,9 +313,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       __syncthreads();
       er.template store_rows<TW>(p, wl, wm * 64 + hb * 32, oy0, ox0);
     }
+#ifdef DMH_STAMPS
+    STAMP(5)  // epilogue
+    if (p.stats && lane == 0 && blockIdx.y == 0) {
+      const int stiles = ((p.Hout + 7) / 8) * p.tilesX;
+      unsigned long long* d = reinterpret_cast<unsigned long long*>(
+                                  p.stats + ((size_t)(b * stiles + (ty * (TH / 8)) * p.tilesX + tx) * p.Cout) * 2) + wave * 8;
+      for (int i = 0; i < 6; ++i) d[i] = tk[i];
+      d[6] = t_now - t_begin;
+      d[7] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+    }
+#else
     er.template write_stats_grid<WM, WN, TH>(p, lds, ty, tx);
+#endif
   }
 }
+#undef STAMP
 
 // ------------------------------------------------------------------------------ weight packing
 // per-output-channel scale: 2^k with max |w| * 2^k in [2^14, 2^15); oscale[c] = 2^-k (1 for padded / all-zero channels)

@@ -159,6 +159,22 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         shape = (batch_size, self.channels, self.image_size, self.image_size)
         return self.ddim_sample(shape) if self.is_ddim_sampling else self.p_sample_loop(shape)
 
+    @torch.no_grad()
+    def interpolate(self, x1, x2, t=None, lam=0.5):
+        """DDP:737-754: q_sample both images at step t, blend, denoise with p_sample down to 0.
+        The reference assigns p_sample's (pred_img, x_start) TUPLE back to ``img`` (DDP:750-752 vs 661), so its loop
+        cannot run past the first step; the evident intent — carry pred_img — is implemented."""
+        b = x1.shape[0]
+        t = default(t, self.num_timesteps - 1)
+        assert x1.shape == x2.shape
+        t_batched = torch.full((b,), t, device=x1.device, dtype=torch.long)
+        xt1, xt2 = self.q_sample(x1, t_batched), self.q_sample(x2, t_batched)
+        img = ops.lerp(xt1, xt2, float(lam))                               # (1 - lam) * xt1 + lam * xt2
+        host = self._host()
+        for i in reversed(range(0, t)):
+            img, _ = self.p_sample(img, i, _host=host)
+        return img
+
     def q_sample(self, x_start, t, noise=None):
         """DDP:756-761."""
         noise = default(noise, lambda: self.rng.randn(x_start.shape, x_start.device))

@@ -259,6 +259,14 @@ def affine(x, scale, shift):
     return y
 
 
+def lerp(a, b, lam):
+    """(1 - lam) * a + lam * b  (DDP:746) on the q_sample kernel."""
+    B = a.shape[0]
+    ca = torch.full((B,), 1.0 - lam, device=a.device, dtype=torch.float32)
+    cb = torch.full((B,), lam, device=a.device, dtype=torch.float32)
+    return q_sample(a.contiguous(), b.contiguous(), ca, cb)
+
+
 def affine_tail_(x, c0, scale, shift):
     B, Cc, H, W = x.shape
     call('dmh_affine_tail', ptr(x), B, Cc, H * W, c0, float(scale), float(shift))

@@ -283,3 +283,25 @@ def test_unet_ddp_fullsize_vs_oracle():
     with torch.no_grad():
         ref = OU.ddp_unet_forward(sd, x, t, xs, True)
     close('ddp full', m(g(x), g(t), g(xs)).cpu(), ref, rtol=1e-3, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_ddp_interpolate_matches_manual_chain():
+    """DDP:737-754 (with pred_img carried, see the docstring): q_sample both ends, blend, p_sample chain"""
+    from dmhomo_amd import ddpm, ops
+    torch.manual_seed(3)
+    m = ddpm.Unet(dim=8, dim_mults=(1, 2), channels=6).cuda()
+    d = ddpm.GaussianDiffusion(m, image_size=16, timesteps=50, sampling_timesteps=50, loss_type='l1',
+                               objective='pred_x0').cuda()
+    x1, x2 = torch.rand(2, 6, 16, 16, device='cuda') * 2 - 1, torch.rand(2, 6, 16, 16, device='cuda') * 2 - 1
+    draws = [torch.randn(2, 6, 16, 16) for _ in range(2 + 4)]
+    d.rng = ReplayDeviceRng(draws)
+    got = d.interpolate(x1, x2, t=4, lam=0.25)
+    d.rng = ReplayDeviceRng(draws)
+    tb = torch.full((2,), 4, device='cuda', dtype=torch.long)
+    a, b = d.q_sample(x1, tb), d.q_sample(x2, tb)
+    img = 0.75 * a + 0.25 * b
+    for i in reversed(range(4)):
+        img, _ = d.p_sample(img, i)
+    assert got.shape == x1.shape and torch.isfinite(got).all()
+    torch.testing.assert_close(got, img, rtol=1e-5, atol=1e-5)
