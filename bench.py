@@ -165,12 +165,16 @@ def main():
     if rank == 0:
         images = args.bs * world * args.steps
         res = {
-            'metric': 'sampled images/sec (128x128, s_step=32)', 'value': images / elapsed, 'unit': 'images/s',
+            'metric': f'sampled images/sec ({args.image_size}x{args.image_size}, s_step={args.s_step})', 'value': images / elapsed, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_denoise_step': elapsed / args.steps / args.s_step * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'DGM CFG-Unet dim={args.dim} {args.image_size}x{args.image_size} '
-                                   f'bs={args.bs}/GPU s_step={args.s_step} cond_scale=3 (BASELINE configs[1])',
+                                   f'bs={args.bs}/GPU s_step={args.s_step} cond_scale=3 ' + (
+                                       '(BASELINE configs[1])' if (args.dim, args.image_size, args.bs, args.s_step) ==
+                                       (64, 128, 25, 32) else '(BASELINE configs[4], stress)' if
+                                       (args.dim, args.image_size, args.bs, args.s_step) == (128, 256, 8, 250) else
+                                       '(non-BASELINE configuration)'),
                        'global_batch': args.bs * world, 'sharding': f'samples x{world}, no data-path collective',
                        'weights': 'seeded random init', 'noise': 'device Philox'},
         }

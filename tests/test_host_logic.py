@@ -89,3 +89,27 @@ def test_product_does_not_import_the_oracle():
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.stdout.strip() == 'False', out.stdout + out.stderr
+
+
+def test_record_files_split_into_the_hem_sample_format(tmp_path):
+    """row 2 of SURVEY 8f: dgm_sample's list-of-dict record (SAMPLE:73-77) -> one {"img12", "homo12"} file per sample
+    (GEN:36-47), readable the way HEM/dataset/data_loader.py:123-131 reads it"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'gen_split', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts',
+                                  'generate_nyps_to_single_case.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    rng = np.random.default_rng(0)
+    recs = [{'imgs': rng.integers(0, 256, (3, 6, 8, 8), dtype=np.uint8), 'homos': rng.standard_normal((3, 3, 3))}
+            for _ in range(2)]
+    src = tmp_path / 'dataset'
+    src.mkdir()
+    np.save(str(src / 'idx_0_rank_0_part_0_dm_cahomo_0.006k.npy'), recs)
+    n = gen.split_records(sorted(str(p) for p in src.glob('*npy*')), str(tmp_path / 'samples'), verbose=False)
+    assert n == 6
+    for k in range(1, 7):
+        buf = np.load(str(tmp_path / 'samples' / f'{k}.npy'), allow_pickle=True).item()      # as the HEM loader does
+        r, i = divmod(k - 1, 3)
+        assert buf['img12'].dtype == np.uint8 and np.array_equal(buf['img12'], recs[r]['imgs'][i])
+        assert buf['homo12'].dtype == np.float64 and np.array_equal(buf['homo12'], recs[r]['homos'][i])
