@@ -429,16 +429,17 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = expf(acc[db][nbn][r] - m);
+          const float e = __expf(acc[db][nbn][r] - m);  // hardware exp2: ~1e-7 relative, as in pass 1
           acc[db][nbn][r] = e;
           s += e;
         }
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
+      const float rs = scale / s;  // one division per pixel column instead of 32 (softmax * scale, CFG:262-263)
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[db][nbn][r] = (acc[db][nbn][r] / s) * scale;
+        for (int r = 0; r < 4; ++r) acc[db][nbn][r] *= rs;
     }
     // ---- out^T[e][n] = sum_d ctx[d][e] q'[n][d]
     float4v yacc[4][4];  // FUSE: this head's part of to_out: rows c (cb, 4*kg + r), columns = pixels
