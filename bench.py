@@ -176,7 +176,11 @@ def main():
                                        (args.dim, args.image_size, args.bs, args.s_step) == (128, 256, 8, 250) else
                                        '(non-BASELINE configuration)'),
                        'global_batch': args.bs * world, 'sharding': f'samples x{world}, no data-path collective',
-                       'weights': 'seeded random init', 'noise': 'device Philox'},
+                       'weights': 'seeded random init', 'noise': 'device Philox',
+                       'arithmetic': 'fp32 tensors; 3x3 / 1x1 convolutions and the attention projections multiply block-scaled '
+                                     'fp16 pieces of the fp32 operands on the matrix cores (3 MFMAs per product block, '
+                                     'fp32 accumulate, error at the fp32-accumulation level: DESIGN.md 3.1); '
+                                     'DMH_CONV3_VARIANT=6 selects the exact-fp32 kernels'},
         }
         if log:
             fl3 = ms3 = n3 = 0.0
