@@ -324,6 +324,10 @@ static int conv3_variant() {
 
 // the fp16-piece kernel serves 3x3 and 1x1 stride-1 convolutions when variant 9 (the default) is selected
 static bool use_f16x3(int KH, int stride) { return conv3_variant() == 9 && stride == 1 && (KH == 3 || KH == 1); }
+// ... and the 4x4 / stride-2 Downsample conv as a 2x2 conv over a space-to-depth view, when the shape allows it
+static bool use_f16x3_s2d(int KH, int stride, int C0, int C1) {
+  return conv3_variant() == 9 && KH == 4 && stride == 2 && C1 == 0 && C0 % 32 == 0;
+}
 
 static int conv_out_dim(int in, int KH, int stride, int ups) {
   if (ups) return in * 2;
@@ -351,7 +355,8 @@ extern "C" int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack_floats(Cout, C0, C1);
   if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack_floats(Cout, C0, C1, KH, KW);
   if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack_floats(Cout, C0, C1);
-  if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1)) return dmh_f16x3_pack_floats(Cout, C0, C1, KH, KW);
+  if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1) || use_f16x3_s2d(KH, 2, C0, C1))
+    return dmh_f16x3_pack_floats(Cout, C0, C1, KH, KW);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 64 * KC;
@@ -365,7 +370,8 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
   if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
   if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
-  if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1)) return dmh_f16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
+  if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1) || use_f16x3_s2d(KH, 2, C0, C1))
+    return dmh_f16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
   const int KC = conv_kc_v(KH, stride);
   const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
@@ -423,7 +429,12 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
     case 710: return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);
-    case 420: return launch_conv<4, 4, 2, 0, 16, 8, 16>(d, Hout, Wout, st);
+    case 420:
+      if (use_f16x3_s2d(4, 2, d->C0, d->src1 ? d->C1 : 0)) {
+        DMH_REQUIRE(!d->in_coef, "dmh_conv2d: the 4x4 / stride-2 conv takes no GroupNorm prologue");
+        return dmh_f16x3_launch(d, Hout, Wout, st);
+      }
+      return launch_conv<4, 4, 2, 0, 16, 8, 16>(d, Hout, Wout, st);
     case 220:
       DMH_REQUIRE(d->Hin % 2 == 0 && d->Win % 2 == 0, "dmh_conv2d: 2x2/s2 needs even input size");
       return launch_conv<2, 2, 2, 0, 16, 8, 16>(d, Hout, Wout, st);

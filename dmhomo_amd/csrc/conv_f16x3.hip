@@ -30,8 +30,13 @@
 //       prefetched one K step ahead.
 // Epilogue: shared with conv.hip (LDS transpose, + bias, + residual, float4 NHWC stores, GroupNorm partials).
 //
-// Replaces: the 3x3 convolutions of Block / ResnetBlock CFG:128-170, the Upsample conv CFG:106-107 and the
-// 1x1 convolutions (to_qkv / to_out / res_conv) of CFG:176-245.
+// UPS == 2 is the Downsample conv (4x4, stride 2, pad 1, CFG:110-111) as an exact 2x2 / stride-1 convolution over the
+// space-to-depth view of its input shifted by one pixel: X[cy][cx][(py, px, c)] = x[2cy-1+py][2cx-1+px][c], so
+// y[oy][ox] = sum_{dy,dx in {0,1}} W[2dy+py][2dx+px] X[oy+dy][ox+dx] — the view is only index math in the halo gather
+// (a 'channel chunk' is then 32 channels of one of the four pixel parities), the weights are re-indexed at pack time.
+//
+// Replaces: the 3x3 convolutions of Block / ResnetBlock CFG:128-170, the Upsample conv CFG:106-107, the Downsample
+// conv CFG:110-111 and the 1x1 convolutions (to_qkv / to_out / res_conv) of CFG:176-245.
 #include <stdlib.h>
 
 #include "common.h"
@@ -56,7 +61,7 @@ struct F16Cfg {
   static constexpr int IN_W = (TW - 1) * S + KW;
   static constexpr int IN_PIX = IN_H * IN_W;
   static constexpr int NLOAD = (IN_PIX * 8 + 255) / 256;
-  static constexpr int PAD = (S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0);
+  static constexpr int PAD = UPS == 2 ? 0 : ((S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0));  // UPS == 2: cell (oy, ox) is tap (0,0)
   // An A fragment of v_mfma_f32_16x16x32_f16 is 16 pixels of one tile row x 4 K-groups of 16 B.  ds_read_b128 serves
   // lanes in groups of 16 that pair 8 pixels of one K-group with the complementary 8 pixels of the next K-group
   // (MI355X_MICROARCH.md, LDS): with a pixel pitch of 10 x 16 B those 16 lanes fall on 16 distinct 16 B bank groups.
@@ -97,8 +102,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - Cfg::PAD, ix0 = ox0 * S - Cfg::PAD;
-  const int Hlim = UPS ? p.Hin * 2 : p.Hin;
-  const int Wlim = UPS ? p.Win * 2 : p.Win;
+  const int Hlim = UPS == 1 ? p.Hin * 2 : (UPS == 2 ? p.Hin / 2 + 1 : p.Hin);  // UPS == 2: coarse cells 0 .. Hin/2
+  const int Wlim = UPS == 1 ? p.Win * 2 : (UPS == 2 ? p.Win / 2 + 1 : p.Win);
 
   if (tid < 2) mxslot[tid] = 0u;
 #ifdef DMH_STAMPS
@@ -163,16 +168,35 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
     const bool ok = pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
     const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
-    const int sy = UPS ? (yc >> 1) : yc, sx = UPS ? (xc >> 1) : xc;
-    poff[i] = (b * p.Hin + sy) * p.Win + sx;
+    const int sy = UPS == 1 ? (yc >> 1) : yc, sx = UPS == 1 ? (xc >> 1) : xc;
+    poff[i] = UPS == 2 ? ((yc << 16) | xc) : (b * p.Hin + sy) * p.Win + sx;  // UPS == 2: the coarse cell, resolved per parity
     inside |= (ok ? 1u : 0u) << i;
   }
+  unsigned inside_ch = inside;  // validity mask of the chunk whose loads are in flight (UPS == 2: depends on the parity)
   auto issue_chunk_loads = [&](int ch) {
     const bool s1 = ch >= p.nch0;
     const float* src = s1 ? p.src1 : p.src0;
     const int Csrc = s1 ? p.C1 : p.C0;
     const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
     const int cc = c < Csrc ? c : 0;
+    if (UPS == 2) {
+      // chunk = (pixel parity, 32 channels): source pixel (2*cy - 1 + py, 2*cx - 1 + px) of coarse cell (cy, cx)
+      const int nchc = p.C0 / KC, par = ch / nchc;
+      const int py = par >> 1, px = par & 1;
+      const int c2 = (ch - par * nchc) * KC + c4 * 4;
+      inside_ch = 0u;
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        const int ry = 2 * (poff[i] >> 16) - 1 + py, rx = 2 * (poff[i] & 0xffff) - 1 + px;
+        const bool ok = ((inside >> i) & 1u) && ry >= 0 && ry < p.Hin && rx >= 0 && rx < p.Win;
+        const int yc = min(max(ry, 0), p.Hin - 1), xc = min(max(rx, 0), p.Win - 1);
+        v[i] = ld4(src + ((size_t)(b * p.Hin + yc) * p.Win + xc) * Csrc + c2);
+        inside_ch |= (ok ? 1u : 0u) << i;
+      }
+      ca = make_float4(1.f, 1.f, 1.f, 1.f);
+      cb = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) v[i] = ld4(src + (size_t)poff[i] * Csrc + cc);
     ca = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -190,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const bool s1c = ch >= p.nch0;
     const bool pro = (p.in_coef != nullptr) && !s1c;
-    const bool cvalid = (s1c ? ch - p.nch0 : ch) * KC + c4 * 4 < (s1c ? p.C1 : p.C0);
-    const unsigned msk = cvalid ? inside : 0u;
+    const bool cvalid = UPS == 2 || (s1c ? ch - p.nch0 : ch) * KC + c4 * 4 < (s1c ? p.C1 : p.C0);
+    const unsigned msk = cvalid ? inside_ch : 0u;
     // ---- values of this chunk (prologue applied, padding zeroed) stay in v[]; their largest magnitude -> LDS slot
     unsigned mx = 0u;
 #pragma unroll
@@ -352,9 +376,11 @@ __global__ __launch_bounds__(64) void f16x3_wscale_kernel(const float* __restric
 
 // fp16 element index: ((((((nt * nchunks + ch) * NTAPS + tap) * 2 + nh) * 2 + nb) * 2 + plane) * 64 + lane) * 8 + j
 //   -> plane (g1, g2) of w[o = nt*64 + nh*32 + nb*16 + (lane & 15)][c = chunk channel (lane >> 4)*8 + j][tap] * 2^k
+// s2d: w is the 4x4 / stride-2 weight [Cout][C0][4][4]; the packed conv is 2x2 over 4*C0 channels ordered (py, px, c):
+//      W2[o][(py, px, c)][dy][dx] = w[o][c][2*dy + py][2*dx + px]   (nch0 = 4 * C0 / 32 chunks)
 __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const float* __restrict__ oscale,
                                          _Float16* __restrict__ wp, int Cout, int C0, int C1, int NTAPS, int nch0,
-                                         int nch1, int64_t total) {
+                                         int nch1, int64_t total, int s2d) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int64_t r = idx;
@@ -385,13 +411,21 @@ __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const floa
     c += C0;
   }
   float ws = 0.f;
-  if (ok && o < Cout) ws = w[((size_t)o * (C0 + C1) + c) * NTAPS + tap] / oscale[o];  // exact: a power of two
+  if (s2d) {
+    const int nchc = C0 / KC, par = ch / nchc;
+    const int cr = (ch - par * nchc) * KC + k;  // real input channel
+    const int ky = 2 * (tap >> 1) + (par >> 1), kx = 2 * (tap & 1) + (par & 1);
+    if (o < Cout) ws = w[((size_t)o * C0 + cr) * 16 + ky * 4 + kx] / oscale[o];
+  } else if (ok && o < Cout) {
+    ws = w[((size_t)o * (C0 + C1) + c) * NTAPS + tap] / oscale[o];  // exact: a power of two
+  }
   const _Float16 g1 = (_Float16)ws;
   const _Float16 g2 = (_Float16)(ws - (float)g1);
   wp[idx] = plane == 0 ? g1 : g2;
 }
 
 static int64_t f16x3_frag_floats(int Cout, int C0, int C1, int KH, int KW) {
+  if (KH == 4) return (int64_t)cdiv(Cout, 64) * (4 * C0 / KC) * 4 * 2 * STEP_U4 * 4;  // as 2x2 over 4*C0 channels
   return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 2 * STEP_U4 * 4;
 }
 
@@ -400,14 +434,15 @@ int64_t dmh_f16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW) {
 }
 
 int dmh_f16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st) {
-  const int nch0 = cdiv(C0, KC), nch1 = cdiv(C1, KC);
+  const bool s2d = KH == 4;
+  const int nch0 = s2d ? 4 * C0 / KC : cdiv(C0, KC), nch1 = s2d ? 0 : cdiv(C1, KC);
   const int64_t frag = f16x3_frag_floats(Cout, C0, C1, KH, KW);
   float* oscale = wpack + frag;
   hipLaunchKernelGGL(f16x3_wscale_kernel, dim3(cdiv(Cout, 64) * 64), dim3(64), 0, st, w, oscale, Cout,
                      (C0 + C1) * KH * KW);
   const int64_t total = frag * 2;  // fp16 elements
   hipLaunchKernelGGL(pack_f16x3_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, w, oscale,
-                     reinterpret_cast<_Float16*>(wpack), Cout, C0, C1, KH * KW, nch0, nch1, total);
+                     reinterpret_cast<_Float16*>(wpack), Cout, C0, C1, s2d ? 4 : KH * KW, nch0, nch1, total, s2d ? 1 : 0);
   DMH_CHECK_LAUNCH("dmh_pack_conv_weight(f16x3)");
   return DMH_OK;
 }
@@ -416,7 +451,8 @@ template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
 static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   using Cfg = F16Cfg<KH, KW, S, UPS, TH, TW, WM, WN>;
   ConvArgs a = fill_conv_args(d, Hout, Wout, KC, TH, TW);
-  a.oscale = d->wpack + f16x3_frag_floats(d->Cout, a.C0, a.C1, KH, KW);
+  if (UPS == 2) a.nch0 = 4 * a.C0 / KC;  // (parity, 32-channel) chunks of the space-to-depth view
+  a.oscale = d->wpack + f16x3_frag_floats(d->Cout, a.C0, a.C1, UPS == 2 ? 4 : KH, UPS == 2 ? 4 : KW);
 #ifdef DMH_STAMPS
   if (const char* e = getenv("DMH_WINO_ABLATE")) a.ablate = atoi(e);
 #endif
@@ -438,6 +474,10 @@ static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
 // channels per workgroup (half the staging per flop); otherwise 16x16 pixels x 64 channels.
 int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   const bool wide = d->Cout % 128 == 0;
+  if (d->KH == 4) {  // Downsample: 2x2 over the shifted space-to-depth view
+    return wide ? launch_f16x3<2, 2, 1, 2, 8, 16, 2, 2>(d, Hout, Wout, st)
+                : launch_f16x3<2, 2, 1, 2, 16, 16, 4, 1>(d, Hout, Wout, st);
+  }
   if (d->KH == 1) {
     static int wide1 = -1;  // development knob
     if (wide1 < 0) {

@@ -39,6 +39,9 @@ CONV_CASES = [
     ('4x4s2 64->128 32x32', 2, 32, 32, 64, 0, 128, 4, 2, 0),
     ('4x4s2 ragged 8->16 22x38', 1, 22, 38, 8, 0, 16, 4, 2, 0),
     ('2x2s2 16->32 24x40', 2, 24, 40, 16, 0, 32, 2, 2, 0),
+    ('4x4s2 64->64 32x48 (space-to-depth on the fp16 cores)', 2, 32, 48, 64, 0, 64, 4, 2, 0),
+    ('4x4s2 ragged 64->128 21x35', 1, 21, 35, 64, 0, 128, 4, 2, 0),
+    ('4x4s2 128->256 16x16', 2, 16, 16, 128, 0, 256, 4, 2, 0),
     ('3x3 tiny 4x4 256->512', 2, 4, 4, 256, 0, 512, 3, 1, 0),
 ]
 
