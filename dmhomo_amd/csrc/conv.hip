@@ -323,7 +323,9 @@ static int conv3_variant() {
 }
 
 // the fp16-piece kernel serves 3x3 and 1x1 stride-1 convolutions when variant 9 (the default) is selected
-static bool use_f16x3(int KH, int stride) { return conv3_variant() == 9 && stride == 1 && (KH == 3 || KH == 1); }
+static bool use_f16x3(int KH, int stride) {
+  return conv3_variant() == 9 && stride == 1 && (KH == 3 || KH == 1 || KH == 7);
+}
 // ... and the 4x4 / stride-2 Downsample conv as a 2x2 conv over a space-to-depth view, when the shape allows it
 static bool use_f16x3_s2d(int KH, int stride, int C0, int C1) {
   return conv3_variant() == 9 && KH == 4 && stride == 2 && C1 == 0 && C0 % 32 == 0;
@@ -428,7 +430,9 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 9: return dmh_f16x3_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
-    case 710: return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);
+    case 710:
+      if (use_f16x3(7, 1)) return dmh_f16x3_launch(d, Hout, Wout, st);
+      return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);
     case 420:
       if (use_f16x3_s2d(4, 2, d->C0, d->src1 ? d->C1 : 0)) {
         DMH_REQUIRE(!d->in_coef, "dmh_conv2d: the 4x4 / stride-2 conv takes no GroupNorm prologue");

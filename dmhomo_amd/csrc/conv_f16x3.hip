@@ -478,6 +478,9 @@ int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
     return wide ? launch_f16x3<2, 2, 1, 2, 8, 16, 2, 2>(d, Hout, Wout, st)
                 : launch_f16x3<2, 2, 1, 2, 16, 16, 4, 1>(d, Hout, Wout, st);
   }
+  if (d->KH == 7)  // init conv (CFG:333): few input channels, so most of each 32-channel K slice is zero padding — still
+                   // ~3x the fp32 MFMA kernel
+    return launch_f16x3<7, 7, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);
   if (d->KH == 1) {
     static int wide1 = -1;  // development knob
     if (wide1 < 0) {
