@@ -48,14 +48,20 @@ int dmh_ws_standardize(const float* w, float* w_out, int Cout, int K, float eps,
 /* number of floats of the packed image of an OIHW weight for dmh_conv2d */
 int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW);
 
-/* OIHW [Cout][C0+C1][KH][KW] -> tile-major image [ntile][chunk][tap][64][KC] consumed by
- * dmh_conv2d (KC = 32 input channels per chunk, 16 for the 7x7 / strided variants; chunks
- * never straddle the two concatenated sources; padding is zero). */
+/* OIHW [Cout][C0+C1][KH][KW] -> the image dmh_conv2d consumes (an opaque blob of dmh_conv_pack_floats floats; pack
+ * again whenever the weight changes).  Default kernels (3x3, 1x1, 7x7, 4x4/stride 2): every output channel scaled by
+ * a power of two, split into two fp16 planes and stored in MFMA-fragment order, followed by the per-channel 2^-k
+ * (dmhomo_amd/csrc/conv_f16x3.hip); exact-fp32 kernels (2x2/stride 2, channel counts that are not a multiple of 32
+ * for the strided conv, or DMH_CONV3_VARIANT != 9): tile-major fp32 [ntile][chunk][tap][64][KC].  Chunks never
+ * straddle the two concatenated sources; padding is zero. */
 int dmh_pack_conv_weight(const float* w_oihw, float* wpack, int Cout, int C0, int C1, int KH, int KW,
                          void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * K1/K2  convolution as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32)
+ * K1/K2  convolution as an implicit GEMM.  fp32 tensors in and out; by default the products run on the fp16
+ * matrix cores with every fp32 operand carried as block-scaled fp16 pieces (three v_mfma_f32_16x16x32_f16 per
+ * product block, fp32 accumulation; error at the level of the fp32 accumulation rounding, fp32 exponent range —
+ * DESIGN.md 3.1).  DMH_CONV3_VARIANT=0..3 / 6 (environment, read once) selects the exact-fp32 MFMA kernels.
  * ------------------------------------------------------------------------------------- */
 typedef struct DmhConv {
   const float* src0; /* NHWC [B][Hin][Win][C0] */
