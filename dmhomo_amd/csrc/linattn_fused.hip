@@ -630,11 +630,13 @@ extern "C" int dmh_linattn_fused_pack(const float* w_qkv, float* wpack, int C, v
 }
 
 static int fused_tiles(int B, int n) {
-  // sub-tiles per workgroup: as many as keep >= ~1024 workgroups in flight (at most 8 = 512 pixels)
+  // sub-tiles per workgroup: a function of n ONLY — the split of a sample's pixels fixes the order of its online-softmax
+  // merges, and a sample's result must not depend on how many other samples share the launch (rows stay bitwise
+  // independent: what makes sharding across GPUs and the two-stream CFG split exact).  64 splits per sample at most.
+  (void)B;
   const int nt = cdiv(n, TP);
-  int t = 8;
-  while (t > 1 && (int64_t)B * cdiv(nt, t) < 1024) t >>= 1;
-  return t;
+  const int t = nt / 64;
+  return t < 1 ? 1 : (t > 8 ? 8 : t);
 }
 
 extern "C" int dmh_linattn_fused_splits(int B, int n) { return cdiv(cdiv(n, TP), fused_tiles(B, n)); }

@@ -124,6 +124,25 @@ def test_unet_rows_are_independent():
     assert torch.equal(full, again)                       # deterministic: no atomics anywhere
 
 
+def test_fullsize_rows_independent_and_cfg_modes_agree():
+    """dim 64 at 128x128 (the bench geometry; fused attention, fp16-piece convolutions with per-tile block scales):
+    a sample's output is bitwise the same alone, inside a larger batch, and whichever way the two CFG passes are
+    scheduled ('batched' = one 2B-row launch sequence, 'streams' = two B-row sequences on two HIP streams)"""
+    m, sd = make_cfg(64)
+    x, rf, mk = _cond_inputs(3, 128, 500)
+    t = torch.full((3,), 967)
+    c = torch.zeros(3, dtype=torch.long)
+    full = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=0.)
+    part = m(g(x[2:]), g(t[2:]), g(c[2:]), g(rf[2:]), g(mk[2:]), cond_drop_prob=0.)
+    assert torch.equal(full[2:], part)
+    outs = {}
+    for mode in ('batched', 'streams'):
+        m.cfg_mode = mode
+        outs[mode] = m.forward_with_cond_scale(g(x), g(t), g(c), g(rf), g(mk), cond_scale=3.).clone()
+    assert torch.isfinite(outs['batched']).all()
+    assert torch.equal(outs['batched'], outs['streams'])
+
+
 def test_unet_weight_update_is_picked_up():
     m, sd = make_cfg(8)
     x, rf, mk = _cond_inputs(1, 16, 300)
