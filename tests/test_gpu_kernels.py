@@ -43,6 +43,12 @@ CONV_CASES = [
     ('4x4s2 ragged 64->128 21x35', 1, 21, 35, 64, 0, 128, 4, 2, 0),
     ('4x4s2 128->256 16x16', 2, 16, 16, 128, 0, 256, 4, 2, 0),
     ('3x3 tiny 4x4 256->512', 2, 4, 4, 256, 0, 512, 3, 1, 0),
+    ('3x3 upsample wide 128->128 12x20', 2, 12, 20, 128, 0, 128, 3, 1, 1),
+    ('3x3 concat wide 128+64->128 17x9', 1, 17, 9, 128, 64, 128, 3, 1, 0),
+    ('3x3 odd channels 36->20 11x13', 2, 11, 13, 36, 0, 20, 3, 1, 0),
+    ('3x3 512->512 2x2 (image smaller than a tile, 16 chunks)', 3, 2, 2, 512, 0, 512, 3, 1, 0),
+    ('1x1 128->64 17x9', 2, 17, 9, 128, 0, 64, 1, 1, 0),
+    ('1x1 tiny 8->8 3x3', 1, 3, 3, 8, 0, 8, 1, 1, 0),
 ]
 
 
@@ -69,6 +75,24 @@ def test_conv2d(ops, case):
     tot = stats.sum(dim=1).cpu().double()
     close(name + ' stats.sum', tot[..., 0], ref.double().sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
     close(name + ' stats.sumsq', tot[..., 1], (ref.double() ** 2).sum(dim=(2, 3)), rtol=1e-4, atol=1e-3)
+
+
+def test_conv3x3_linearity_at_bench_size(ops):
+    """size-independent property at the bench's largest 3x3 geometry (50 rows of 128x128x64): conv is linear in its
+    input — conv(x1 + 2 x2) - b == (conv(x1) - b) + 2 (conv(x2) - b) to fp32 accumulation accuracy, whatever block
+    scales the fp16-piece kernel picks for the three inputs"""
+    B, H, W, C = 50, 128, 128, 64
+    w = (torch.randn((C, C, 3, 3), generator=torch.Generator().manual_seed(60)) * (1.0 / (C * 9)) ** 0.5).to(dev())
+    b = (torch.randn((C,), generator=torch.Generator().manual_seed(61)) * 0.1).to(dev())
+    pc = ops.PackedConv(w, b, C)
+    g1, g2 = torch.Generator(device=dev()).manual_seed(62), torch.Generator(device=dev()).manual_seed(63)
+    x1 = torch.randn((B, H, W, C), generator=g1, device=dev())
+    x2 = torch.randn((B, H, W, C), generator=g2, device=dev()) * 3.0
+    y1, y2, y12 = ops.conv2d(pc, x1), ops.conv2d(pc, x2), ops.conv2d(pc, x1 + 2 * x2)
+    lhs, rhs = y12 - b, (y1 - b) + 2 * (y2 - b)
+    rel = ((lhs - rhs).abs().max() / rhs.abs().max()).item()
+    print(f'[parity] conv3x3 linearity at 50x128x128x64: rel_to_max={rel:.3e}')
+    assert rel < 3e-6, rel
 
 
 RANGE_CASES = [  # name, activation scale per 32-channel group, weight scale per output-channel half
