@@ -50,6 +50,9 @@ SIGNATURES = {
     'dmh_linattn_context': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_linattn_merge': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_linattn_apply': (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
+    'dmh_conv_wgrad_workspace_floats': (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'dmh_conv_wgrad': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, C.c_void_p]),
     'dmh_pixel_stats': (c_int, [c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),
     'dmh_linattn_fused_pack_floats': (c_i64, [c_int]),
     'dmh_linattn_fused_pack': (c_int, [c_f32p, c_f32p, c_int, C.c_void_p]),

@@ -339,3 +339,26 @@ def dlt_homography(flow):
     out = torch.empty((B, 3, 3), device=flow.device, dtype=torch.float64)
     call('dmh_dlt_homography', ptr(flow), ptr(ws, torch.float64), ptr(out, torch.float64), B, H, W)
     return out
+
+
+# ------------------------------------------------------------------ training (first pieces)
+def conv_wgrad(dy, src0, src1=None, k=3, in_coef=None, want_bias=True):
+    """weight (and bias) gradient of the stride-1 kxk conv whose input was cat(src0, src1) (after the optional
+    SiLU(a*src0+b) prologue) and whose output gradient is dy.  NHWC in, OIHW (Cout, C0+C1, k, k) out."""
+    B, H, W, cout = dy.shape
+    c0 = src0.shape[3]
+    c1 = 0 if src1 is None else src1.shape[3]
+    dw = _empty((cout, c0 + c1, k, k), dy)
+    db = _empty((cout,), dy) if want_bias else None
+    work = _empty((lib().dmh_conv_wgrad_workspace_floats(B, H, W, c0, c1, cout, k),), dy)
+    call('dmh_conv_wgrad', ptr(dy), ptr(src0), ptr(src1), ptr(in_coef), ptr(dw), ptr(db), ptr(work), B, H, W, c0, c1,
+         cout, k)
+    return (dw, db) if want_bias else dw
+
+
+def conv_dgrad_pack(w, c_in_total):
+    """PackedConv that computes the DATA gradient of a stride-1 conv with weight w (Cout, Cin, k, k): the same conv
+    kernel on dy with the taps flipped and (Cout, Cin) transposed (no bias)."""
+    wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, k, k)
+    assert wt.shape[0] == c_in_total
+    return PackedConv(wt, None, w.shape[0])

@@ -218,6 +218,20 @@ int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, in
 #define DMH_DLT_BLOCKS 64
 int dmh_dlt_homography(const float* flow, double* ws, double* Hout, int B, int H, int W, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training — first pieces, the rest of the backward pass is not built yet.
+ * ------------------------------------------------------------------------------------- */
+
+/* weight / bias gradient of a stride-1 KHxKH convolution (KH = 1, 3; pad KH/2), i.e. autograd of F.conv2d (CFG:128)
+ * wrt weight and bias:  dw[o][c][ky][kx] = sum dy[b][y][x][o] * X[b][y+ky-p][x+kx-p][c],  db[o] = sum dy[b][y][x][o],
+ * X = cat(src0, src1) with the optional consumer-side prologue X = SiLU(a*src0 + b) of dmh_conv2d.  Exact fp32
+ * (v_mfma_f32_16x16x4_f32), deterministic (pixel splits reduced in a fixed order).  The DATA gradient is dmh_conv2d
+ * itself on dy with the weight flipped in both taps and transposed in (Cout, Cin).
+ * dy: NHWC [B][H][W][Cout]; dw: OIHW [Cout][C0+C1][KH][KH]; db: [Cout] or NULL; work: ..._workspace_floats floats. */
+int64_t dmh_conv_wgrad_workspace_floats(int B, int H, int W, int C0, int C1, int Cout, int KH);
+int dmh_conv_wgrad(const float* dy, const float* src0, const float* src1, const float* in_coef, float* dw, float* db,
+                   float* work, int B, int H, int W, int C0, int C1, int Cout, int KH, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,63 @@
+"""-m gpu parity tests of the training pieces built so far: HIP through the C ABI vs torch autograd
+of the same op on the CPU in fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from gpu_util import dev, nhwc, nchw, rand
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from dmhomo_amd import ops as _ops
+    _ops.lib()
+    return _ops
+
+
+def _rel(name, got, ref):
+    rel = ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+    print(f'[parity] {name}: rel_to_max={rel:.3e} ref_absmax={ref.abs().max().item():.3e}')
+    return rel
+
+
+WG_CASES = [  # name, B, H, W, C0, C1, Cout, k, prologue
+    ('3x3 64->64 16x16', 2, 16, 16, 64, 0, 64, 3, 0),
+    ('3x3 ragged 8->24 19x23', 2, 19, 23, 8, 0, 24, 3, 0),
+    ('3x3 concat 64+32->96 20x12', 2, 20, 12, 64, 32, 96, 3, 0),
+    ('3x3 prologue 32->48 18x21', 2, 18, 21, 32, 0, 48, 3, 1),
+    ('3x3 128->128 33x17', 3, 33, 17, 128, 0, 128, 3, 0),
+    ('1x1 64->384 16x16', 2, 16, 16, 64, 0, 384, 1, 0),
+    ('1x1 concat 40+24->72 5x33', 3, 5, 33, 40, 24, 72, 1, 0),
+]
+
+
+@pytest.mark.parametrize('case', WG_CASES, ids=[c[0] for c in WG_CASES])
+def test_conv_weight_bias_and_data_gradients(ops, case):
+    """dW, db (dmh_conv_wgrad) and dX (dmh_conv2d on dy with the flipped, transposed weight) of a stride-1 conv
+    against autograd"""
+    name, B, H, W, C0, C1, Cout, k, pro = case
+    x = rand((B, C0 + C1, H, W), 70)
+    w = rand((Cout, C0 + C1, k, k), 71, (1.0 / ((C0 + C1) * k * k)) ** 0.5)
+    b = rand((Cout,), 72, 0.1)
+    dy = rand((B, Cout, H, W), 73)
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    coef = None
+    xin = xd
+    if pro:
+        a, bb = 1 + 0.3 * rand((B, C0), 74), 0.5 * rand((B, C0), 75)
+        coef = torch.stack([a, bb], 1).contiguous().to(dev())
+        xin = F.silu(a.double()[:, :, None, None] * xd + bb.double()[:, :, None, None])
+    y = F.conv2d(xin, wd, bd, 1, k // 2)
+    gx, gw, gb = torch.autograd.grad(y, (xin if pro else xd, wd, bd), dy.double())
+    s0 = nhwc(x[:, :C0])
+    s1 = nhwc(x[:, C0:]) if C1 else None
+    dw, db = ops.conv_wgrad(nhwc(dy), s0, s1, k=k, in_coef=coef)
+    assert _rel(name + ' dW', dw, gw) < 2e-6
+    assert _rel(name + ' db', db, gb) < 2e-6
+    if not pro:
+        pd = ops.conv_dgrad_pack(w.to(dev()), C0 + C1)
+        dx = nchw(ops.conv2d(pd, nhwc(dy)))
+        assert _rel(name + ' dX', dx, gx) < 3e-6
