@@ -53,6 +53,13 @@ SIGNATURES = {
     'dmh_conv_wgrad_workspace_floats': (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'dmh_conv_wgrad': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, C.c_void_p]),
+    'dmh_gn_finalize_train': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_int, c_int, c_int,
+                                      c_int, c_float, C.c_void_p]),
+    'dmh_gn_bwd_chunks': (c_int, [c_int]),
+    'dmh_gn_silu_backward': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p,
+                                     c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_sum_over_batch': (c_int, [c_f32p, c_f32p, c_int, c_i64, C.c_void_p]),
+    'dmh_ws_backward': (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
     'dmh_pixel_stats': (c_int, [c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),
     'dmh_linattn_fused_pack_floats': (c_i64, [c_int]),
     'dmh_linattn_fused_pack': (c_int, [c_f32p, c_f32p, c_int, C.c_void_p]),

@@ -10,7 +10,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ ss,
                                                          int64_t ss_stride, float* __restrict__ coef, int C, int groups,
-                                                         int hw, float eps) {
+                                                         int hw, float eps, float* __restrict__ mr) {
   const int b = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cg = C / groups;
   const int lane = threadIdx.x;
@@ -32,6 +32,10 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
+  if (mr && lane == 0) {  // saved for the backward pass: (mean, rstd) of this (sample, group)
+    mr[(size_t)blockIdx.x * 2 + 0] = meanf;
+    mr[(size_t)blockIdx.x * 2 + 1] = rstd;
+  }
   for (int cc = lane; cc < cg; cc += 64) {
     const int c = g * cg + cc;
     float a = rstd * gamma[c];
@@ -134,8 +138,20 @@ extern "C" int dmh_gn_finalize(const float* stats, int tiles, const float* gamma
   DMH_REQUIRE(stats && gamma && beta && coef, "dmh_gn_finalize: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize: bad shape");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
-                     ss, ss_stride, coef, C, groups, hw, eps);
+                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr);
   DMH_CHECK_LAUNCH("dmh_gn_finalize");
+  return DMH_OK;
+}
+
+// same, also saving (mean, rstd) per (sample, group) for the backward pass: mr [B][groups][2]
+extern "C" int dmh_gn_finalize_train(const float* stats, int tiles, const float* gamma, const float* beta,
+                                     const float* ss, int64_t ss_stride, float* coef, float* mr, int B, int C,
+                                     int groups, int hw, float eps, void* stream) {
+  DMH_REQUIRE(stats && gamma && beta && coef && mr, "dmh_gn_finalize_train: null pointer");
+  DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize_train: bad shape");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
+                     ss, ss_stride, coef, C, groups, hw, eps, mr);
+  DMH_CHECK_LAUNCH("dmh_gn_finalize_train");
   return DMH_OK;
 }
 

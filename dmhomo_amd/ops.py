@@ -362,3 +362,50 @@ def conv_dgrad_pack(w, c_in_total):
     wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, k, k)
     assert wt.shape[0] == c_in_total
     return PackedConv(wt, None, w.shape[0])
+
+
+def gn_finalize_train(stats, gamma, beta, hw, groups, ss=None, eps=1e-5):
+    """gn_finalize that also returns mr (B, groups, 2) = (mean, rstd), saved for gn_silu_backward."""
+    B, tiles, Cc, _ = stats.shape
+    coef = _empty((B, 2, Cc), stats)
+    mr = _empty((B, groups, 2), stats)
+    ss_ptr, ss_stride = None, 0
+    if ss is not None:
+        assert ss.stride(1) == 1 and ss.shape[0] == B and ss.shape[1] == 2 * Cc
+        ss_ptr, ss_stride = C.c_void_p(ss.data_ptr()), ss.stride(0)
+    call('dmh_gn_finalize_train', ptr(stats), tiles, ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(coef), ptr(mr), B, Cc,
+         groups, hw, float(eps))
+    return coef, mr
+
+
+def gn_silu_backward(dout, y, coef, mr, gamma, beta, groups, ss=None):
+    """backward of GroupNorm -> (scale+1, shift) -> SiLU: -> dy (B,H,W,C), dgamma (C,), dbeta (C,), dss (B, 2C) = the
+    gradient wrt the (scale, shift) row of the ResnetBlock mlp (zeros are NOT returned when ss is None: dss = None)."""
+    B, H, W, Cc = y.shape
+    hw = H * W
+    dy = _empty(y.shape, y)
+    pg = _empty((B, 4, Cc), y)
+    part = _empty((B, lib().dmh_gn_bwd_chunks(hw), Cc, 2), y)
+    bcoef = _empty((B, 3, Cc), y)
+    ss_ptr, ss_stride = None, 0
+    if ss is not None:
+        assert ss.stride(1) == 1 and ss.shape[0] == B and ss.shape[1] == 2 * Cc
+        ss_ptr, ss_stride = C.c_void_p(ss.data_ptr()), ss.stride(0)
+    call('dmh_gn_silu_backward', ptr(dout), ptr(y), ptr(coef), ptr(mr), ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(dy),
+         ptr(pg), ptr(part), ptr(bcoef), B, hw, Cc, groups)
+    gb = _empty((2, Cc), y)
+    # pg is (B, 4, C): the first 2*C floats of each sample are its (dgamma, dbeta) parts
+    pgv = pg.reshape(B, 4 * Cc)
+    tmp = pgv[:, :2 * Cc].contiguous()
+    call('dmh_sum_over_batch', ptr(tmp), ptr(gb), B, 2 * Cc)
+    dss = pgv[:, 2 * Cc:].contiguous() if ss is not None else None
+    return dy, gb[0], gb[1], dss
+
+
+def ws_backward(w, dwh, eps=1e-5):
+    """gradient wrt the raw weight from the gradient wrt the standardised one (CFG:120-126)."""
+    cout = w.shape[0]
+    w, dwh = w.contiguous(), dwh.contiguous()
+    dw = torch.empty_like(w)
+    call('dmh_ws_backward', ptr(w), ptr(dwh), ptr(dw), cout, w.numel() // cout, float(eps))
+    return dw

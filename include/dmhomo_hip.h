@@ -232,6 +232,24 @@ int64_t dmh_conv_wgrad_workspace_floats(int B, int H, int W, int C0, int C1, int
 int dmh_conv_wgrad(const float* dy, const float* src0, const float* src1, const float* in_coef, float* dw, float* db,
                    float* work, int B, int H, int W, int C0, int C1, int Cout, int KH, void* stream);
 
+/* dmh_gn_finalize that also saves (mean, rstd) per (sample, group) for the backward pass: mr [B][groups][2] */
+int dmh_gn_finalize_train(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
+                          int64_t ss_stride, float* coef, float* mr, int B, int C, int groups, int hw, float eps,
+                          void* stream);
+
+/* backward of Block's GroupNorm -> (scale+1, shift) -> SiLU (CFG:206-212) given the conv output y it normalised:
+ *   dout: gradient wrt SiLU(GN(y)...) [B][HW][C];  y, coef [B][2][C], mr [B][groups][2]: as seen / saved by the forward;
+ *   dy [B][HW][C];  pg [B][4][C]: per-sample parts of (dgamma, dbeta) — add them over b with dmh_sum_over_batch — and
+ *   (d scale, d shift) of the ResnetBlock mlp output;  part [B][dmh_gn_bwd_chunks(HW)][C][2], bcoef [B][3][C]: work. */
+int dmh_gn_bwd_chunks(int HW);
+int dmh_gn_silu_backward(const float* dout, const float* y, const float* coef, const float* mr, const float* gamma,
+                         const float* beta, const float* ss, int64_t ss_stride, float* dy, float* pg, float* part,
+                         float* bcoef, int B, int HW, int C, int groups, void* stream);
+/* out[i] = sum_b in[b][i], i < per (fixed order) */
+int dmh_sum_over_batch(const float* in, float* out, int B, int64_t per, void* stream);
+/* backward of the weight standardisation CFG:120-126: dw from the gradient dwh wrt the standardised weight. [Cout][K] */
+int dmh_ws_backward(const float* w, const float* dwh, float* dw, int Cout, int K, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,3 +61,56 @@ def test_conv_weight_bias_and_data_gradients(ops, case):
         pd = ops.conv_dgrad_pack(w.to(dev()), C0 + C1)
         dx = nchw(ops.conv2d(pd, nhwc(dy)))
         assert _rel(name + ' dX', dx, gx) < 3e-6
+
+
+def _ws(w):
+    m = w.mean(dim=(1, 2, 3), keepdim=True)
+    v = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    return (w - m) * (v + 1e-5).rsqrt()
+
+
+def _ref_block(x, w, b, g, be, ss):
+    y = F.group_norm(F.conv2d(x, _ws(w), b, 1, 1), 8, g, be, 1e-5)
+    if ss is not None:
+        c = y.shape[1]
+        y = y * (ss[:, :c, None, None] + 1) + ss[:, c:, None, None]
+    return F.silu(y)
+
+
+@pytest.mark.parametrize('c0,c1,cout,H,W', [(64, 0, 64, 16, 16), (32, 0, 32, 19, 23), (64, 32, 48, 20, 12),
+                                            (128, 0, 256, 9, 17)])
+def test_resnet_block_backward(ops, c0, c1, cout, H, W):
+    """one whole ResnetBlock (CFG:216-241: two weight-standardised convs, two GroupNorms, scale/shift, SiLU, residual
+    or 1x1 res_conv, fused torch.cat input) forward + backward on the HIP kernels vs torch autograd in fp64"""
+    from dmhomo_amd import train
+    B, cin = 2, c0 + c1
+    P = dict(w1=rand((cout, cin, 3, 3), 80, (1.0 / (cin * 9)) ** 0.5) + 0.01, b1=rand((cout,), 81, 0.1),
+             g1=1 + 0.2 * rand((cout,), 82), be1=0.2 * rand((cout,), 83),
+             w2=rand((cout, cout, 3, 3), 84, (1.0 / (cout * 9)) ** 0.5) + 0.01, b2=rand((cout,), 85, 0.1),
+             g2=1 + 0.2 * rand((cout,), 86), be2=0.2 * rand((cout,), 87))
+    if cin != cout:
+        P['rw'], P['rb'] = rand((cout, cin, 1, 1), 88, cin ** -0.5), rand((cout,), 89, 0.1)
+    x = rand((B, cin, H, W), 90)
+    ss = 0.3 * rand((B, 2 * cout), 91)
+    dout = rand((B, cout, H, W), 92)
+    # ---- reference: autograd in fp64
+    D = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    xd, ssd = x.double().requires_grad_(True), ss.double().requires_grad_(True)
+    h = _ref_block(xd, D['w1'], D['b1'], D['g1'], D['be1'], ssd)
+    h = _ref_block(h, D['w2'], D['b2'], D['g2'], D['be2'], None)
+    out = h + (F.conv2d(xd, D['rw'], D['rb']) if 'rw' in D else xd)
+    names = list(D)
+    grads = torch.autograd.grad(out, [xd, ssd] + [D[k] for k in names], dout.double())
+    ref = dict(zip(['x', 'ss'] + names, grads))
+    # ---- HIP
+    blk = train.ResnetBlockTrain({k: v.to(dev()) for k, v in P.items()}, c0, c1)
+    x0 = nhwc(x[:, :c0])
+    x1 = nhwc(x[:, c0:]) if c1 else None
+    o, saved = blk.forward(x0, x1, ss.to(dev()).contiguous())
+    assert _rel('block out', nchw(o), out.detach()) < 2e-5
+    dx, g = blk.backward(saved, nhwc(dout))
+    tag = f'block {cin}->{cout} {H}x{W}'
+    assert _rel(tag + ' dx', nchw(dx), ref['x']) < 5e-5
+    assert _rel(tag + ' dss', g['ss'], ref['ss']) < 5e-5
+    for k in names:
+        assert _rel(tag + ' d' + k, g[k].reshape(ref[k].shape), ref[k]) < 5e-5, k
