@@ -226,3 +226,131 @@ extern "C" int dmh_ws_backward(const float* w, const float* dwh, float* dw, int 
   DMH_CHECK_LAUNCH("dmh_ws_backward");
   return DMH_OK;
 }
+
+// ------------------------------------------------------------------------------------------ channel LayerNorm backward
+// N4 (CFG:137-141) out = (x - mean_c) * rstd * g [+ res]:  xh = (x - mean)*rstd, dxh = dout*g,
+//   dx = rstd * (dxh - mean_c(dxh) - xh * mean_c(dxh*xh)),   dg[c] = sum_pixels dout*xh   (d res = dout)
+// mean / rstd are recomputed from x (two-pass, as the forward).  LPP lanes share a pixel, NV float4 each; every
+// workgroup also emits its partial dg row (fixed order inside; rows are added by dmh_sum_over_batch).
+template <int LPP, int NV>
+__global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ dout, float* __restrict__ dx,
+                                                                 float* __restrict__ dg_part, int64_t npix, int C,
+                                                                 float eps) {
+  extern __shared__ float red[];  // [256 / LPP pixel groups][C] for the dg reduction
+  const int C4 = C >> 2;
+  const int sub = threadIdx.x % LPP, grp = threadIdx.x / LPP;
+  const int64_t pix_per_block = 256 / LPP;
+  float4 dgacc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) dgacc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t pix = (int64_t)blockIdx.x * pix_per_block + grp; pix < npix; pix += (int64_t)gridDim.x * pix_per_block) {
+    float4 v[NV], d[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      d[j] = v[j];
+      if (q < C4) {
+        v[j] = ld4(x + pix * C + q * 4);
+        d[j] = ld4(dout + pix * C + q * 4);
+      }
+      s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+#pragma unroll
+    for (int off = LPP >> 1; off; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float qsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      if (q < C4) {
+        const float ex = v[j].x - mean, ey = v[j].y - mean, ez = v[j].z - mean, ew = v[j].w - mean;
+        qsum += (ex * ex + ey * ey) + (ez * ez + ew * ew);
+      }
+    }
+#pragma unroll
+    for (int off = LPP >> 1; off; off >>= 1) qsum += __shfl_xor(qsum, off);
+    const float rstd = 1.0f / sqrtf(qsum / (float)C + eps);
+    float m1 = 0.f, m2 = 0.f;
+    float4 xh[NV], dxh[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      xh[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dxh[j] = xh[j];
+      if (q < C4) {
+        const float4 gg = ld4(g + q * 4);
+        xh[j] = make_float4((v[j].x - mean) * rstd, (v[j].y - mean) * rstd, (v[j].z - mean) * rstd, (v[j].w - mean) * rstd);
+        dxh[j] = make_float4(d[j].x * gg.x, d[j].y * gg.y, d[j].z * gg.z, d[j].w * gg.w);
+        m1 += (dxh[j].x + dxh[j].y) + (dxh[j].z + dxh[j].w);
+        m2 += (dxh[j].x * xh[j].x + dxh[j].y * xh[j].y) + (dxh[j].z * xh[j].z + dxh[j].w * xh[j].w);
+        dgacc[j].x = fmaf(d[j].x, xh[j].x, dgacc[j].x);
+        dgacc[j].y = fmaf(d[j].y, xh[j].y, dgacc[j].y);
+        dgacc[j].z = fmaf(d[j].z, xh[j].z, dgacc[j].z);
+        dgacc[j].w = fmaf(d[j].w, xh[j].w, dgacc[j].w);
+      }
+    }
+#pragma unroll
+    for (int off = LPP >> 1; off; off >>= 1) {
+      m1 += __shfl_xor(m1, off);
+      m2 += __shfl_xor(m2, off);
+    }
+    m1 /= (float)C;
+    m2 /= (float)C;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int q = sub + j * LPP;
+      if (q < C4) {
+        float4 o;
+        o.x = rstd * (dxh[j].x - m1 - xh[j].x * m2);
+        o.y = rstd * (dxh[j].y - m1 - xh[j].y * m2);
+        o.z = rstd * (dxh[j].z - m1 - xh[j].z * m2);
+        o.w = rstd * (dxh[j].w - m1 - xh[j].w * m2);
+        st4(dx + pix * C + q * 4, o);
+      }
+    }
+  }
+  // dg of this workgroup: pixel groups added in a fixed order
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int q = sub + j * LPP;
+    if (q < C4) st4(red + (size_t)grp * C + q * 4, dgacc[j]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int gI = 0; gI < (int)pix_per_block; ++gI) s += red[(size_t)gI * C + c];
+    dg_part[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+
+#define DMH_LNB_BLOCKS 256  // partial dg rows
+
+template <int LPP, int NV>
+static int launch_lnb(const float* x, const float* g, const float* dout, float* dx, float* dg_part, int64_t npix, int C,
+                      float eps, hipStream_t st) {
+  const size_t lds = (size_t)(256 / LPP) * C * 4;
+  hipLaunchKernelGGL((chan_layernorm_bwd_kernel<LPP, NV>), dim3(DMH_LNB_BLOCKS), dim3(256), lds, st, x, g, dout, dx,
+                     dg_part, npix, C, eps);
+  DMH_CHECK_LAUNCH("dmh_chan_layernorm_backward");
+  return DMH_OK;
+}
+
+extern "C" int dmh_lnb_blocks(void) { return DMH_LNB_BLOCKS; }
+
+// dx [npix][C]; dg_part [dmh_lnb_blocks()][C] partial rows of dg (add them with dmh_sum_over_batch)
+extern "C" int dmh_chan_layernorm_backward(const float* x, const float* g, const float* dout, float* dx, float* dg_part,
+                                           int64_t npix, int C, float eps, void* stream) {
+  DMH_REQUIRE(x && g && dout && dx && dg_part, "dmh_chan_layernorm_backward: null pointer");
+  DMH_REQUIRE(npix > 0 && C > 0 && C % 4 == 0 && C <= 1024, "dmh_chan_layernorm_backward: unsupported C=%d", C);
+  hipStream_t st = (hipStream_t)stream;
+  const int C4 = C / 4;
+  if (C4 <= 8) return launch_lnb<8, 1>(x, g, dout, dx, dg_part, npix, C, eps, st);
+  if (C4 <= 16) return launch_lnb<16, 1>(x, g, dout, dx, dg_part, npix, C, eps, st);
+  if (C4 <= 32) return launch_lnb<32, 1>(x, g, dout, dx, dg_part, npix, C, eps, st);
+  if (C4 <= 64) return launch_lnb<64, 1>(x, g, dout, dx, dg_part, npix, C, eps, st);
+  if (C4 <= 128) return launch_lnb<64, 2>(x, g, dout, dx, dg_part, npix, C, eps, st);
+  return launch_lnb<64, 4>(x, g, dout, dx, dg_part, npix, C, eps, st);
+}

@@ -409,3 +409,16 @@ def ws_backward(w, dwh, eps=1e-5):
     dw = torch.empty_like(w)
     call('dmh_ws_backward', ptr(w), ptr(dwh), ptr(dw), cout, w.numel() // cout, float(eps))
     return dw
+
+
+def chan_layernorm_backward(x, g, dout, eps=1e-5):
+    """backward of chan_layernorm (without its residual input, whose gradient is dout itself) -> dx, dg."""
+    Cc = x.shape[-1]
+    x, dout = x.contiguous(), dout.contiguous()
+    dx = torch.empty_like(x)
+    nb = lib().dmh_lnb_blocks()
+    part = _empty((nb, Cc), x)
+    call('dmh_chan_layernorm_backward', ptr(x), ptr(g), ptr(dout), ptr(dx), ptr(part), x.numel() // Cc, Cc, float(eps))
+    dg = _empty((Cc,), x)
+    call('dmh_sum_over_batch', ptr(part), ptr(dg), nb, Cc)
+    return dx, dg

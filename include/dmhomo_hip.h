@@ -250,6 +250,12 @@ int dmh_sum_over_batch(const float* in, float* out, int B, int64_t per, void* st
 /* backward of the weight standardisation CFG:120-126: dw from the gradient dwh wrt the standardised weight. [Cout][K] */
 int dmh_ws_backward(const float* w, const float* dwh, float* dw, int Cout, int K, float eps, void* stream);
 
+/* backward of the channel LayerNorm N4 (CFG:137-141): dx [npix][C] and dmh_lnb_blocks() partial rows of dg
+ * (dg_part [blocks][C]; add them with dmh_sum_over_batch).  d res = dout when the forward added a residual. */
+int dmh_lnb_blocks(void);
+int dmh_chan_layernorm_backward(const float* x, const float* g, const float* dout, float* dx, float* dg_part,
+                                int64_t npix, int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,3 +114,18 @@ def test_resnet_block_backward(ops, c0, c1, cout, H, W):
     assert _rel(tag + ' dss', g['ss'], ref['ss']) < 5e-5
     for k in names:
         assert _rel(tag + ' d' + k, g[k].reshape(ref[k].shape), ref[k]) < 5e-5, k
+
+
+@pytest.mark.parametrize('C,H,W', [(64, 16, 16), (8, 5, 7), (128, 9, 11), (512, 4, 4)])
+def test_chan_layernorm_backward(ops, C, H, W):
+    x = rand((2, C, H, W), 100) * 1.5 + 0.3
+    g = 1 + 0.2 * rand((C,), 101)
+    dout = rand((2, C, H, W), 102)
+    xd, gd = x.double().requires_grad_(True), g.double().requires_grad_(True)
+    m = xd.mean(1, keepdim=True)
+    v = xd.var(1, unbiased=False, keepdim=True)
+    out = (xd - m) * (v + 1e-5).rsqrt() * gd[None, :, None, None]
+    gx, gg = torch.autograd.grad(out, (xd, gd), dout.double())
+    dx, dg = ops.chan_layernorm_backward(nhwc(x), g.to(dev()), nhwc(dout))
+    assert _rel(f'LN bwd C={C} dx', nchw(dx), gx) < 5e-6
+    assert _rel(f'LN bwd C={C} dg', dg, gg) < 5e-6
