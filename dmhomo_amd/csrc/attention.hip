@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
 
 // merge the splits: M = max m; S = sum s*exp(m-M); ctx = sum ctx*exp(m-M) / S / n
 __global__ __launch_bounds__(1024) void linattn_merge_kernel(const float* __restrict__ partial,
-                                                             float* __restrict__ ctx, int n, int nsplit) {
+                                                             float* __restrict__ ctx, int n, int nsplit,
+                                                             float* __restrict__ ms) {
   const int bh = blockIdx.x;  // b*4 + h
   const int b = bh >> 2, h = bh & 3;
   const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
@@ -83,6 +84,10 @@ __global__ __launch_bounds__(1024) void linattn_merge_kernel(const float* __rest
     acc = fmaf(base[sp * stride + 64 + d * 32 + e], w, acc);
   }
   ctx[(size_t)bh * 1024 + d * 32 + e] = acc / S / (float)n;
+  if (ms && e == 0) {  // saved for the backward pass: softmax-over-n statistics of k
+    ms[((size_t)bh * 32 + d) * 2 + 0] = M;
+    ms[((size_t)bh * 32 + d) * 2 + 1] = S;
+  }
 }
 
 // pass 2: out[p][h*32+e] = sum_d ctx[d][e] * q'[p][d],  q' = softmax_d(q[p]) * scale.
@@ -273,7 +278,7 @@ extern "C" int dmh_linattn_context(const float* qkv, float* partial, int B, int 
 extern "C" int dmh_linattn_merge(const float* partial, float* ctx, int B, int n, void* stream) {
   DMH_REQUIRE(partial && ctx && B > 0 && n > 0, "dmh_linattn_merge: bad arguments");
   hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n,
-                     dmh_linattn_splits(n));
+                     dmh_linattn_splits(n), (float*)nullptr);
   DMH_CHECK_LAUNCH("dmh_linattn_merge");
   return DMH_OK;
 }
@@ -281,8 +286,18 @@ extern "C" int dmh_linattn_merge(const float* partial, float* ctx, int B, int n,
 // same merge for partials produced with another split count (linattn_fused.hip)
 extern "C" int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, void* stream) {
   DMH_REQUIRE(partial && ctx && B > 0 && n > 0 && nsplit > 0, "dmh_linattn_merge_n: bad arguments");
-  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n, nsplit);
+  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n, nsplit,
+                     (float*)nullptr);
   DMH_CHECK_LAUNCH("dmh_linattn_merge_n");
+  return DMH_OK;
+}
+
+// dmh_linattn_merge that also saves ms [B][4][32][2] = (max, sum exp) of k over the pixels, for dmh_linattn_backward
+extern "C" int dmh_linattn_merge_ms(const float* partial, float* ctx, float* ms, int B, int n, void* stream) {
+  DMH_REQUIRE(partial && ctx && ms && B > 0 && n > 0, "dmh_linattn_merge_ms: bad arguments");
+  hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n,
+                     dmh_linattn_splits(n), ms);
+  DMH_CHECK_LAUNCH("dmh_linattn_merge_ms");
   return DMH_OK;
 }
 

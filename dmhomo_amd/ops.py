@@ -422,3 +422,30 @@ def chan_layernorm_backward(x, g, dout, eps=1e-5):
     dg = _empty((Cc,), x)
     call('dmh_sum_over_batch', ptr(part), ptr(dg), nb, Cc)
     return dx, dg
+
+
+def linear_attention_core_train(qkv, scale):
+    """linear_attention_core that also returns what its backward needs: (out, saved)."""
+    B, H, W, c = qkv.shape
+    assert c == 384
+    n = H * W
+    partial = _empty((lib().dmh_linattn_partial_floats(B, n),), qkv)
+    ctx = _empty((B, 4, 32, 32), qkv)
+    ms = _empty((B, 4, 32, 2), qkv)
+    out = _empty((B, H, W, 128), qkv)
+    call('dmh_linattn_context', ptr(qkv), ptr(partial), B, n)
+    call('dmh_linattn_merge_ms', ptr(partial), ptr(ctx), ptr(ms), B, n)
+    call('dmh_linattn_apply', ptr(qkv), ptr(ctx), ptr(out), B, n, float(scale))
+    return out, dict(qkv=qkv, ctx=ctx, ms=ms, scale=float(scale))
+
+
+def linear_attention_core_backward(sv, dout):
+    """gradient wrt qkv (B,H,W,384) of the LinearAttention core from the gradient wrt its output (B,H,W,128)."""
+    qkv = sv['qkv']
+    B, H, W, _ = qkv.shape
+    n = H * W
+    dqkv = torch.empty_like(qkv)
+    work = _empty((lib().dmh_linattn_bwd_workspace_floats(B, n),), qkv)
+    call('dmh_linattn_backward', ptr(qkv), ptr(sv['ctx']), ptr(sv['ms']), ptr(dout.contiguous()), ptr(dqkv), ptr(work), B, n,
+         sv['scale'])
+    return dqkv

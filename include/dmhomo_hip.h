@@ -256,6 +256,14 @@ int dmh_lnb_blocks(void);
 int dmh_chan_layernorm_backward(const float* x, const float* g, const float* dout, float* dx, float* dg_part,
                                 int64_t npix, int C, float eps, void* stream);
 
+/* backward of the LinearAttention core (CFG:258-269) on a stored qkv [B][n][384]:  forward with dmh_linattn_context,
+ * dmh_linattn_merge_ms (saves ms [B][4][32][2], the softmax-over-n statistics of k), dmh_linattn_apply;  then
+ * dmh_linattn_backward(dout [B][n][128]) -> dqkv [B][n][384].  work: dmh_linattn_bwd_workspace_floats(B, n) floats. */
+int dmh_linattn_merge_ms(const float* partial, float* ctx, float* ms, int B, int n, void* stream);
+int64_t dmh_linattn_bwd_workspace_floats(int B, int n);
+int dmh_linattn_backward(const float* qkv, const float* ctx, const float* ms, const float* dout, float* dqkv, float* work,
+                         int B, int n, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,3 +129,23 @@ def test_chan_layernorm_backward(ops, C, H, W):
     dx, dg = ops.chan_layernorm_backward(nhwc(x), g.to(dev()), nhwc(dout))
     assert _rel(f'LN bwd C={C} dx', nchw(dx), gx) < 5e-6
     assert _rel(f'LN bwd C={C} dg', dg, gg) < 5e-6
+
+
+@pytest.mark.parametrize('H,W', [(16, 16), (7, 9), (24, 40), (4, 4)])
+def test_linear_attention_core_backward(ops, H, W):
+    B = 2
+    qkv = rand((B, 384, H, W), 110) * 1.5
+    dout = rand((B, 128, H, W), 111)
+    qd = qkv.double().requires_grad_(True)
+    n = H * W
+    q, k, v = [t.reshape(B, 4, 32, n) for t in qd.chunk(3, dim=1)]
+    q = q.softmax(dim=-2) * 32 ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum('b h d n, b h e n -> b h d e', k, v / n)
+    out = torch.einsum('b h d e, b h d n -> b h e n', ctx, q).reshape(B, 128, H, W)
+    (gq,) = torch.autograd.grad(out, (qd,), dout.double())
+    o, sv = ops.linear_attention_core_train(nhwc(qkv), 32 ** -0.5)
+    assert _rel(f'linattn core fwd {H}x{W}', nchw(o), out.detach()) < 1e-5
+    dqkv = nchw(ops.linear_attention_core_backward(sv, nhwc(dout)))
+    for name, sl in (('dq', slice(0, 128)), ('dk', slice(128, 256)), ('dv', slice(256, 384))):
+        assert _rel(f'linattn bwd {H}x{W} {name}', dqkv[:, sl], gq[:, sl]) < 2e-5, name
