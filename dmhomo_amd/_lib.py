@@ -65,6 +65,10 @@ SIGNATURES = {
     'dmh_linattn_merge_ms': (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_linattn_bwd_workspace_floats': (c_i64, [c_int, c_int]),
     'dmh_linattn_backward': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
+    'dmh_bgemm': (c_int, [c_f32p, C.POINTER(c_i64), c_f32p, C.POINTER(c_i64), c_f32p, C.POINTER(c_i64), c_int, c_int, c_int,
+                          c_int, c_int, c_float, C.c_void_p]),
+    'dmh_softmax_rows': (c_int, [c_f32p, c_f32p, c_i64, c_int, C.c_void_p]),
+    'dmh_softmax_rows_backward': (c_int, [c_f32p, c_f32p, c_i64, c_int, C.c_void_p]),
     'dmh_pixel_stats': (c_int, [c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),
     'dmh_linattn_fused_pack_floats': (c_i64, [c_int]),
     'dmh_linattn_fused_pack': (c_int, [c_f32p, c_f32p, c_int, C.c_void_p]),

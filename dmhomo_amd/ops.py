@@ -449,3 +449,54 @@ def linear_attention_core_backward(sv, dout):
     call('dmh_linattn_backward', ptr(qkv), ptr(sv['ctx']), ptr(sv['ms']), ptr(dout.contiguous()), ptr(dqkv), ptr(work), B, n,
          sv['scale'])
     return dqkv
+
+
+def _strides4(*v):
+    return (C.c_int64 * 4)(*v)
+
+
+def bgemm(a, sa, b, sb, c, sc, M, N, K, nbo, nbi, alpha=1.0):
+    """c[bo][bi] = alpha * a[bo][bi] (MxK) @ b[bo][bi] (KxN); sa/sb/sc = (outer batch, inner batch, row, column) strides in
+    floats; a, b, c: tensors or (tensor, float offset) pairs."""
+    def base(t):
+        if isinstance(t, tuple):
+            return C.c_void_p(t[0].data_ptr() + 4 * t[1])
+        return ptr(t)
+    call('dmh_bgemm', base(a), _strides4(*sa), base(b), _strides4(*sb), base(c), _strides4(*sc), M, N, K, nbo, nbi,
+         float(alpha))
+
+
+def attention_core_train(qkv, scale):
+    """bottleneck Attention core (CFG:287-295) on the small-GEMM kernels, keeping P = softmax(sim): (out (B,H,W,128), saved)."""
+    B, H, W, c = qkv.shape
+    assert c == 384
+    n = H * W
+    S = _empty((B, 4, n, n), qkv)
+    # sim[i][j] = scale * sum_d q[i][d] k[j][d]
+    bgemm(qkv, (n * 384, 32, 384, 1), (qkv, 128), (n * 384, 32, 1, 384), S, (4 * n * n, n * n, n, 1), n, n, 32, B, 4, scale)
+    P = torch.empty_like(S)
+    call('dmh_softmax_rows', ptr(S), ptr(P), B * 4 * n, n)
+    out = _empty((B, H, W, 128), qkv)
+    # out[i][h*32+d] = sum_j P[i][j] v[j][d]
+    bgemm(P, (4 * n * n, n * n, n, 1), (qkv, 256), (n * 384, 32, 384, 1), out, (n * 128, 32, 128, 1), n, 32, n, B, 4)
+    return out, dict(qkv=qkv, P=P, scale=float(scale))
+
+
+def attention_core_backward(sv, dout):
+    """gradient wrt qkv (B,H,W,384) of the Attention core from the gradient wrt its output (B,H,W,128)."""
+    qkv, P, scale = sv['qkv'], sv['P'], sv['scale']
+    B, H, W, _ = qkv.shape
+    n = H * W
+    dout = dout.contiguous()
+    dqkv = torch.empty_like(qkv)
+    sP, sQ, sO = (4 * n * n, n * n, n, 1), (n * 384, 32, 384, 1), (n * 128, 32, 128, 1)
+    # dv[j][d] = sum_i P[i][j] dout[i][d]
+    bgemm(P, (4 * n * n, n * n, 1, n), dout, sO, (dqkv, 256), sQ, n, 32, n, B, 4)
+    # dP[i][j] = sum_d dout[i][d] v[j][d]
+    dP = torch.empty_like(P)
+    bgemm(dout, sO, (qkv, 256), (n * 384, 32, 1, 384), dP, sP, n, n, 32, B, 4)
+    call('dmh_softmax_rows_backward', ptr(P), ptr(dP), B * 4 * n, n)          # dP <- dsim
+    # dq[i][d] = scale * sum_j dsim[i][j] k[j][d] ;  dk[j][d] = scale * sum_i dsim[i][j] q[i][d]
+    bgemm(dP, sP, (qkv, 128), sQ, dqkv, sQ, n, 32, n, B, 4, scale)
+    bgemm(dP, (4 * n * n, n * n, 1, n), qkv, sQ, (dqkv, 128), sQ, n, 32, n, B, 4, scale)
+    return dqkv

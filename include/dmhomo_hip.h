@@ -264,6 +264,14 @@ int64_t dmh_linattn_bwd_workspace_floats(int B, int n);
 int dmh_linattn_backward(const float* qkv, const float* ctx, const float* ms, const float* dout, float* dqkv, float* work,
                          int B, int n, float scale, void* stream);
 
+/* small strided batched fp32 GEMM (exact fp32 MFMA) for the backward pass: C[bo][bi] = alpha * A[bo][bi] (MxK) * B[bo][bi]
+ * (KxN); sa / sb / sc: HOST arrays of 4 strides in floats {outer batch, inner batch, row, column}.  Row softmax and its
+ * backward (dP <- P * (dP - sum_j dP*P), in place) for the bottleneck Attention (CFG:287-295). */
+int dmh_bgemm(const float* A, const int64_t* sa, const float* B, const int64_t* sb, float* C, const int64_t* sc, int M,
+              int N, int K, int nbo, int nbi, float alpha, void* stream);
+int dmh_softmax_rows(const float* S, float* P, int64_t rows, int n, void* stream);
+int dmh_softmax_rows_backward(const float* P, float* dP, int64_t rows, int n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,3 +149,21 @@ def test_linear_attention_core_backward(ops, H, W):
     dqkv = nchw(ops.linear_attention_core_backward(sv, nhwc(dout)))
     for name, sl in (('dq', slice(0, 128)), ('dk', slice(128, 256)), ('dv', slice(256, 384))):
         assert _rel(f'linattn bwd {H}x{W} {name}', dqkv[:, sl], gq[:, sl]) < 2e-5, name
+
+
+@pytest.mark.parametrize('H,W', [(16, 16), (7, 9), (4, 4)])
+def test_attention_core_forward_backward_small_gemm(ops, H, W):
+    B = 2
+    qkv = rand((B, 384, H, W), 120) * 1.5
+    dout = rand((B, 128, H, W), 121)
+    qd = qkv.double().requires_grad_(True)
+    n = H * W
+    q, k, v = [t.reshape(B, 4, 32, n) for t in qd.chunk(3, dim=1)]
+    sim = torch.einsum('b h d i, b h d j -> b h i j', q * 32 ** -0.5, k)
+    out = torch.einsum('b h i j, b h d j -> b h i d', sim.softmax(dim=-1), v).permute(0, 1, 3, 2).reshape(B, 128, H, W)
+    (gq,) = torch.autograd.grad(out, (qd,), dout.double())
+    o, sv = ops.attention_core_train(nhwc(qkv), 32 ** -0.5)
+    assert _rel(f'attn fwd {H}x{W}', nchw(o), out.detach()) < 1e-5
+    dqkv = nchw(ops.attention_core_backward(sv, nhwc(dout)))
+    for name, sl in (('dq', slice(0, 128)), ('dk', slice(128, 256)), ('dv', slice(256, 384))):
+        assert _rel(f'attn bwd {H}x{W} {name}', dqkv[:, sl], gq[:, sl]) < 2e-5, name
