@@ -52,7 +52,10 @@ SIGNATURES = {
     'dmh_linattn_apply': (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
     'dmh_conv_wgrad_workspace_floats': (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'dmh_conv_wgrad': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, C.c_void_p]),
+                               c_int, c_int, c_int, C.c_void_p]),
+    'dmh_s2d_shift': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_d2s': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_sumpool2': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
     'dmh_gn_finalize_train': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_int, c_int, c_int,
                                       c_int, c_float, C.c_void_p]),
     'dmh_gn_bwd_chunks': (c_int, [c_int]),

@@ -342,17 +342,18 @@ def dlt_homography(flow):
 
 
 # ------------------------------------------------------------------ training (first pieces)
-def conv_wgrad(dy, src0, src1=None, k=3, in_coef=None, want_bias=True):
+def conv_wgrad(dy, src0, src1=None, k=3, in_coef=None, want_bias=True, ups=0):
     """weight (and bias) gradient of the stride-1 kxk conv whose input was cat(src0, src1) (after the optional
-    SiLU(a*src0+b) prologue) and whose output gradient is dy.  NHWC in, OIHW (Cout, C0+C1, k, k) out."""
+    SiLU(a*src0+b) prologue; ups=1: after a nearest x2 upsampling; k=2: 'valid' conv over the space-to-depth view) and
+    whose output gradient is dy.  NHWC in, OIHW (Cout, C0+C1, k, k) out."""
     B, H, W, cout = dy.shape
     c0 = src0.shape[3]
     c1 = 0 if src1 is None else src1.shape[3]
     dw = _empty((cout, c0 + c1, k, k), dy)
     db = _empty((cout,), dy) if want_bias else None
     work = _empty((lib().dmh_conv_wgrad_workspace_floats(B, H, W, c0, c1, cout, k),), dy)
-    call('dmh_conv_wgrad', ptr(dy), ptr(src0), ptr(src1), ptr(in_coef), ptr(dw), ptr(db), ptr(work), B, H, W, c0, c1,
-         cout, k)
+    call('dmh_conv_wgrad', ptr(dy.contiguous()), ptr(src0), ptr(src1), ptr(in_coef), ptr(dw), ptr(db), ptr(work), B, H, W,
+         c0, c1, cout, k, int(ups))
     return (dw, db) if want_bias else dw
 
 
@@ -500,3 +501,47 @@ def attention_core_backward(sv, dout):
     bgemm(dP, sP, (qkv, 128), sQ, dqkv, sQ, n, 32, n, B, 4, scale)
     bgemm(dP, (4 * n * n, n * n, 1, n), qkv, sQ, (dqkv, 128), sQ, n, 32, n, B, 4, scale)
     return dqkv
+
+
+def conv_up_backward(dy, x, w, dpack=None):
+    """backward of Upsample = nearest x2 -> conv3x3 (CFG:106-107): dy (B,2H,2W,Cout), x (B,H,W,C) -> dx, dw, db."""
+    B, H, W, c = x.shape
+    dpack = dpack or conv_dgrad_pack(w, c)
+    gup = conv2d(dpack, dy)                                             # gradient wrt the upsampled tensor
+    dx = torch.empty_like(x)
+    call('dmh_sumpool2', ptr(gup), ptr(dx), B, H, W, c)
+    dw, db = conv_wgrad(dy, x, k=3, ups=1)
+    return dx, dw, db
+
+
+# Downsample 4x4 / stride 2 / pad 1: for input row parity r the taps (ky, row offset a) that reach it
+_DOWN_K = {0: {-1: 3, 0: 1}, 1: {0: 2, 1: 0}}
+
+
+def conv_down_dgrad_pack(w):
+    """PackedConv of the 3x3 conv over dy that yields the data gradient of the 4x4/stride-2 conv in pixel-shuffle
+    layout: out[m][l][(ry*2+rx)*C + c] = dx[2m+ry][2l+rx][c]."""
+    cout, c = w.shape[0], w.shape[1]
+    w3 = torch.zeros((4 * c, cout, 3, 3), device=w.device, dtype=torch.float32)
+    for ry in (0, 1):
+        for rx in (0, 1):
+            par = ry * 2 + rx
+            for a, ky in _DOWN_K[ry].items():
+                for b, kx in _DOWN_K[rx].items():
+                    w3[par * c:(par + 1) * c, :, a + 1, b + 1] = w[:, :, ky, kx].t()
+    return PackedConv(w3, None, cout)
+
+
+def conv_down_backward(dy, x, w, dpack=None):
+    """backward of Downsample = conv 4x4 / stride 2 / pad 1 (CFG:110-111): dy (B,H/2,W/2,Cout), x (B,H,W,C) -> dx, dw, db"""
+    B, H, W, c = x.shape
+    cout = dy.shape[3]
+    dpack = dpack or conv_down_dgrad_pack(w)
+    g4 = conv2d(dpack, dy)                                              # (B, H/2, W/2, 4C)
+    dx = torch.empty_like(x)
+    call('dmh_d2s', ptr(g4), ptr(dx), B, H // 2, W // 2, c)
+    X = _empty((B, H // 2 + 1, W // 2 + 1, 4 * c), x)
+    call('dmh_s2d_shift', ptr(x.contiguous()), ptr(X), B, H, W, c)
+    dw2, db = conv_wgrad(dy, X, k=2)                                    # (Cout, 4C, 2, 2): [(py,px,c)][dy][dx]
+    dw = dw2.view(cout, 2, 2, c, 2, 2).permute(0, 3, 4, 1, 5, 2).reshape(cout, c, 4, 4).contiguous()
+    return dx, dw, db

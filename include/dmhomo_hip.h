@@ -222,15 +222,26 @@ int dmh_dlt_homography(const float* flow, double* ws, double* Hout, int B, int H
  * Training — first pieces, the rest of the backward pass is not built yet.
  * ------------------------------------------------------------------------------------- */
 
-/* weight / bias gradient of a stride-1 KHxKH convolution (KH = 1, 3; pad KH/2), i.e. autograd of F.conv2d (CFG:128)
- * wrt weight and bias:  dw[o][c][ky][kx] = sum dy[b][y][x][o] * X[b][y+ky-p][x+kx-p][c],  db[o] = sum dy[b][y][x][o],
- * X = cat(src0, src1) with the optional consumer-side prologue X = SiLU(a*src0 + b) of dmh_conv2d.  Exact fp32
- * (v_mfma_f32_16x16x4_f32), deterministic (pixel splits reduced in a fixed order).  The DATA gradient is dmh_conv2d
- * itself on dy with the weight flipped in both taps and transposed in (Cout, Cin).
+/* weight / bias gradient of a stride-1 KHxKH convolution, i.e. autograd of F.conv2d (CFG:128) wrt weight and bias:
+ *   dw[o][c][ky][kx] = sum dy[b][y][x][o] * X[b][y+ky-p][x+kx-p][c],  db[o] = sum dy[b][y][x][o],
+ * X = cat(src0, src1) with the optional consumer-side prologue X = SiLU(a*src0 + b) of dmh_conv2d.
+ *   KH = 1, 3, 7: 'same' conv (p = KH/2); ups = 1 (KH = 3): the conv saw the nearest x2 upsampling of the stored
+ *                 input [B][H/2][W/2][C0] (Upsample, CFG:106-107);
+ *   KH = 2      : 'valid' 2x2 conv (p = 0) over a stored input [B][H+1][W+1][C0] — the space-to-depth form
+ *                 (dmh_s2d_shift) of the 4x4 / stride-2 Downsample conv (CFG:110-111).
+ * Exact fp32 (v_mfma_f32_16x16x4_f32), deterministic (pixel splits reduced in a fixed order).  The DATA gradient is
+ * dmh_conv2d itself on dy with the weight flipped in both taps and transposed in (Cout, Cin).
  * dy: NHWC [B][H][W][Cout]; dw: OIHW [Cout][C0+C1][KH][KH]; db: [Cout] or NULL; work: ..._workspace_floats floats. */
 int64_t dmh_conv_wgrad_workspace_floats(int B, int H, int W, int C0, int C1, int Cout, int KH);
 int dmh_conv_wgrad(const float* dy, const float* src0, const float* src1, const float* in_coef, float* dw, float* db,
-                   float* work, int B, int H, int W, int C0, int C1, int Cout, int KH, void* stream);
+                   float* work, int B, int H, int W, int C0, int C1, int Cout, int KH, int ups, void* stream);
+/* layout helpers of the strided / upsampled convs' backward:
+ *   dmh_s2d_shift  X[b][cy][cx][(py*2+px)*C + c] = x[b][2cy-1+py][2cx-1+px][c] (0 outside), [B][H/2+1][W/2+1][4C]
+ *   dmh_d2s        out[b][2m+ry][2l+rx][c] = in[b][m][l][(ry*2+rx)*C + c]        [B][H][W][4C] -> [B][2H][2W][C]
+ *   dmh_sumpool2   out[b][m][l][c] = sum of the 2x2 block of in                  [B][2H][2W][C] -> [B][H][W][C] */
+int dmh_s2d_shift(const float* x, float* X, int B, int H, int W, int C, void* stream);
+int dmh_d2s(const float* in, float* out, int B, int H, int W, int C, void* stream);
+int dmh_sumpool2(const float* in, float* out, int B, int H, int W, int C, void* stream);
 
 /* dmh_gn_finalize that also saves (mean, rstd) per (sample, group) for the backward pass: mr [B][groups][2] */
 int dmh_gn_finalize_train(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,

@@ -167,3 +167,42 @@ def test_attention_core_forward_backward_small_gemm(ops, H, W):
     dqkv = nchw(ops.attention_core_backward(sv, nhwc(dout)))
     for name, sl in (('dq', slice(0, 128)), ('dk', slice(128, 256)), ('dv', slice(256, 384))):
         assert _rel(f'attn bwd {H}x{W} {name}', dqkv[:, sl], gq[:, sl]) < 2e-5, name
+
+
+def test_init_conv_7x7_weight_gradient(ops):
+    B, H, W, C, Co = 2, 21, 18, 12, 64
+    x, w, b, dy = rand((B, C, H, W), 130), rand((Co, C, 7, 7), 131, 0.05), rand((Co,), 132, 0.1), rand((B, Co, H, W), 133)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gw, gb = torch.autograd.grad(F.conv2d(x.double(), wd, bd, 1, 3), (wd, bd), dy.double())
+    dw, db = ops.conv_wgrad(nhwc(dy), nhwc(x), k=7)
+    assert _rel('7x7 dW', dw, gw) < 2e-6 and _rel('7x7 db', db, gb) < 2e-6
+
+
+@pytest.mark.parametrize('C,Co,H,W', [(64, 64, 16, 16), (32, 48, 12, 20), (128, 256, 8, 8)])
+def test_downsample_conv_backward(ops, C, Co, H, W):
+    """Downsample (conv 4x4 / stride 2 / pad 1, CFG:110-111): dX through a 3x3 conv over dy + pixel shuffle, dW through the
+    2x2 form over the shifted space-to-depth view"""
+    B = 2
+    x, w, b = rand((B, C, H, W), 140), rand((Co, C, 4, 4), 141, (1.0 / (C * 16)) ** 0.5), rand((Co,), 142, 0.1)
+    dy = rand((B, Co, H // 2, W // 2), 143)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    gx, gw, gb = torch.autograd.grad(F.conv2d(xd, wd, bd, 2, 1), (xd, wd, bd), dy.double())
+    dx, dw, db = ops.conv_down_backward(nhwc(dy), nhwc(x), w.to(dev()))
+    assert _rel('down dX', nchw(dx), gx) < 3e-6
+    assert _rel('down dW', dw, gw) < 3e-6
+    assert _rel('down db', db, gb) < 3e-6
+
+
+@pytest.mark.parametrize('C,Co,H,W', [(128, 64, 8, 8), (32, 16, 7, 9)])
+def test_upsample_conv_backward(ops, C, Co, H, W):
+    """Upsample (nearest x2 -> conv3x3, CFG:106-107)"""
+    B = 2
+    x, w, b = rand((B, C, H, W), 150), rand((Co, C, 3, 3), 151, (1.0 / (C * 9)) ** 0.5), rand((Co,), 152, 0.1)
+    dy = rand((B, Co, 2 * H, 2 * W), 153)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y = F.conv2d(F.interpolate(xd, scale_factor=2, mode='nearest'), wd, bd, 1, 1)
+    gx, gw, gb = torch.autograd.grad(y, (xd, wd, bd), dy.double())
+    dx, dw, db = ops.conv_up_backward(nhwc(dy), nhwc(x), w.to(dev()))
+    assert _rel('up dX', nchw(dx), gx) < 3e-6
+    assert _rel('up dW', dw, gw) < 3e-6
+    assert _rel('up db', db, gb) < 3e-6
