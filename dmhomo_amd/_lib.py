@@ -72,6 +72,16 @@ SIGNATURES = {
                           c_int, c_int, c_float, C.c_void_p]),
     'dmh_softmax_rows': (c_int, [c_f32p, c_f32p, c_i64, c_int, C.c_void_p]),
     'dmh_softmax_rows_backward': (c_int, [c_f32p, c_f32p, c_i64, c_int, C.c_void_p]),
+    'dmh_act': (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_int, C.c_void_p]),
+    'dmh_class_embed_backward': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_loss_backward': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
+                                  C.c_void_p]),
+    'dmh_sumsq_blocks': (c_int, []),
+    'dmh_sumsq': (c_int, [c_f32p, c_i64, c_f32p, C.c_void_p]),
+    'dmh_gradnorm_finalize': (c_int, [c_f32p, c_int, c_float, c_f32p, C.c_void_p]),
+    'dmh_adam': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_float, c_float, c_float, c_float, c_int,
+                         C.c_void_p]),
+    'dmh_ema': (c_int, [c_f32p, c_f32p, c_i64, c_float, C.c_void_p]),
     'dmh_pixel_stats': (c_int, [c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),
     'dmh_linattn_fused_pack_floats': (c_i64, [c_int]),
     'dmh_linattn_fused_pack': (c_int, [c_f32p, c_f32p, c_int, C.c_void_p]),

@@ -545,3 +545,34 @@ def conv_down_backward(dy, x, w, dpack=None):
     dw2, db = conv_wgrad(dy, X, k=2)                                    # (Cout, 4C, 2, 2): [(py,px,c)][dy][dx]
     dw = dw2.view(cout, 2, 2, c, 2, 2).permute(0, 3, 4, 1, 5, 2).reshape(cout, c, 4, 4).contiguous()
     return dx, dw, db
+
+
+def act(x, mode, dy=None):
+    """mode 'silu' | 'gelu': f(x), or dy * f'(x) when dy is given."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    call('dmh_act', ptr(x), ptr(None if dy is None else dy.contiguous()), ptr(out), x.numel(), {'silu': 1, 'gelu': 2}[mode])
+    return out
+
+
+def add(a, b):
+    """a + b (elementwise, same shape) on the q_sample kernel."""
+    B = a.shape[0]
+    one = torch.ones((B,), device=a.device, dtype=torch.float32)
+    return q_sample(a.contiguous(), b.contiguous(), one, one)
+
+
+def linear_backward(x, w, dy, want_bias=True):
+    """y = x @ w.T (+ b), x (B,in), w (out,in), dy (B,out) -> dx (B,in), dw (out,in), db (out,)"""
+    Bn, cin = x.shape
+    cout = w.shape[0]
+    x, dy, w = x.contiguous(), dy.contiguous(), w.contiguous()
+    dx = _empty((Bn, cin), x)
+    dw = _empty((cout, cin), x)
+    bgemm(dy, (0, 0, cout, 1), w, (0, 0, cin, 1), dx, (0, 0, cin, 1), Bn, cin, cout, 1, 1)
+    bgemm(dy, (0, 0, 1, cout), x, (0, 0, cin, 1), dw, (0, 0, cin, 1), cout, cin, Bn, 1, 1)
+    db = None
+    if want_bias:
+        db = _empty((cout,), x)
+        call('dmh_sum_over_batch', ptr(dy), ptr(db), Bn, cout)
+    return dx, dw, db

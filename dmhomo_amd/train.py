@@ -75,3 +75,369 @@ class ResnetBlockTrain:
             dres = dout                                                   # identity residual
         dx = ops.conv2d(self.d1, dy1, res=dres)                           # data gradient of conv1 + the residual path
         return dx, g
+
+
+# =====================================================================================================================
+# the whole conditional UNet (CFG:302-466): forward with saved activations + backward, on the HIP kernels
+# =====================================================================================================================
+HEADS, DIM_HEAD = 4, 32
+SCALE = DIM_HEAD ** -0.5
+
+
+class _LinAttn:
+    """Residual(PreNorm(LinearAttention)) (CFG:96-103, 246-269) or, with linear=False, Residual(PreNorm(Attention))
+    (CFG:273-296), on a stored qkv tensor."""
+
+    def __init__(self, p, c, linear):
+        self.p, self.c, self.linear = p, c, linear
+        self.fq = ops.PackedConv(p['qkv'], None, c)
+        self.dq = ops.conv_dgrad_pack(p['qkv'], c)
+        self.fo = ops.PackedConv(p['ow'], p['ob'], HEADS * DIM_HEAD)
+        self.do = ops.conv_dgrad_pack(p['ow'], HEADS * DIM_HEAD)
+
+    def forward(self, x):
+        p = self.p
+        xn = ops.chan_layernorm(x, p['g'])
+        qkv = ops.conv2d(self.fq, xn)
+        if self.linear:
+            o, core = ops.linear_attention_core_train(qkv, SCALE)
+            y = ops.conv2d(self.fo, o)
+            out = ops.chan_layernorm(y, p['og'], res=x)
+        else:
+            o, core = ops.attention_core_train(qkv, SCALE)
+            y = None
+            out = ops.conv2d(self.fo, o, res=x)
+        return out, dict(x=x, xn=xn, o=o, y=y, core=core)
+
+    def backward(self, sv, dout):
+        p, g = self.p, {}
+        dout = dout.contiguous()
+        if self.linear:
+            dy, g['og'] = ops.chan_layernorm_backward(sv['y'], p['og'], dout)
+        else:
+            dy = dout
+        g['ow'], g['ob'] = ops.conv_wgrad(dy, sv['o'], k=1)
+        do = ops.conv2d(self.do, dy)
+        dqkv = (ops.linear_attention_core_backward if self.linear else ops.attention_core_backward)(sv['core'], do)
+        g['qkv'] = ops.conv_wgrad(dqkv, sv['xn'], k=1, want_bias=False)
+        dxn = ops.conv2d(self.dq, dqkv)
+        dx, g['g'] = ops.chan_layernorm_backward(sv['x'], p['g'], dxn)
+        return ops.add(dx, dout), g                                        # + the residual path
+
+
+class _Conv:
+    """plain biased conv of the trunk: kind 'same3' (3x3), 'down4' (4x4 / stride 2), 'up3' (nearest x2 + 3x3), 'init7'."""
+
+    def __init__(self, w, b, kind, c):
+        self.w, self.b, self.kind, self.c = w, b, kind, c
+        k = w.shape[-1]
+        self.f = ops.PackedConv(w, b, c, 0, 2 if kind == 'down4' else 1, 1 if kind == 'up3' else 0)
+        self.d = None
+        if kind in ('same3', 'up3'):
+            self.d = ops.conv_dgrad_pack(w, c)
+        elif kind == 'down4':
+            self.d = ops.conv_down_dgrad_pack(w)
+        self.k = k
+
+    def forward(self, x):
+        return ops.conv2d(self.f, x), x
+
+    def backward(self, x, dy, want_dx=True):
+        if self.kind == 'down4':
+            return ops.conv_down_backward(dy, x, self.w, self.d)
+        if self.kind == 'up3':
+            return ops.conv_up_backward(dy, x, self.w, self.d)
+        dw, db = ops.conv_wgrad(dy, x, k=self.k)
+        dx = ops.conv2d(self.d, dy) if (want_dx and self.d is not None) else None
+        return dx, dw, db
+
+
+class UnetTrain:
+    """forward (saving activations) and backward of classifier_free_guidance.Unet on the HIP kernels.
+    ``module``: a dmhomo_amd.cfg.Unet (same parameter names as the reference).  Gradients come back as
+    {parameter name: tensor of the parameter's shape}."""
+
+    def __init__(self, module, groups=8):
+        self.module, self.groups = module, groups
+        self.refresh()
+
+    def refresh(self):
+        sd = {k: v.detach().to(torch.float32).contiguous() for k, v in self.module.named_parameters()}
+        self.sd = sd
+        self.dim = sd['time_mlp.1.weight'].shape[1]
+        half = self.dim // 2
+        import math
+        self.freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(sd['init_conv.weight'].device)
+        dev = sd['init_conv.weight'].device
+        w0 = sd['init_conv.weight']
+        self.cin = w0.shape[1]
+        self.cin_pad = (self.cin + 3) // 4 * 4
+        wp = torch.zeros((w0.shape[0], self.cin_pad, 7, 7), device=dev)
+        wp[:, :self.cin] = w0
+        self.init = _Conv(wp, sd['init_conv.bias'], 'init7', self.cin_pad)
+        self.blocks, self.ss_off, self.ss_total = {}, {}, 0
+
+        def res(prefix, c0, c1=0):
+            p = dict(w1=sd[prefix + '.block1.proj.weight'], b1=sd[prefix + '.block1.proj.bias'],
+                     g1=sd[prefix + '.block1.norm.weight'], be1=sd[prefix + '.block1.norm.bias'],
+                     w2=sd[prefix + '.block2.proj.weight'], b2=sd[prefix + '.block2.proj.bias'],
+                     g2=sd[prefix + '.block2.norm.weight'], be2=sd[prefix + '.block2.norm.bias'])
+            if (prefix + '.res_conv.weight') in sd:
+                p['rw'], p['rb'] = sd[prefix + '.res_conv.weight'], sd[prefix + '.res_conv.bias']
+            blk = ResnetBlockTrain(p, c0, c1, self.groups)
+            self.blocks[prefix] = blk
+            self.ss_off[prefix] = self.ss_total
+            self.ss_total += 2 * blk.cout
+            return blk
+
+        def attn(prefix, c, linear):
+            p = dict(g=sd[prefix + '.fn.norm.g'].reshape(-1).contiguous(), qkv=sd[prefix + '.fn.fn.to_qkv.weight'])
+            if linear:
+                p['ow'], p['ob'] = sd[prefix + '.fn.fn.to_out.0.weight'], sd[prefix + '.fn.fn.to_out.0.bias']
+                p['og'] = sd[prefix + '.fn.fn.to_out.1.g'].reshape(-1).contiguous()
+            else:
+                p['ow'], p['ob'] = sd[prefix + '.fn.fn.to_out.weight'], sd[prefix + '.fn.fn.to_out.bias']
+            a = _LinAttn(p, c, linear)
+            self.blocks[prefix] = a
+            return a
+
+        ns = 1 + max(int(k.split('.')[1]) for k in sd if k.startswith('downs.'))
+        self.ns = ns
+        c = w0.shape[0]
+        self.init_dim = c
+        skip_c = []
+        for i in range(ns):
+            pfx = f'downs.{i}'
+            b1 = res(pfx + '.0', c)
+            skip_c.append(c)
+            res(pfx + '.1', c)
+            attn(pfx + '.2', c, True)
+            skip_c.append(c)
+            w = sd[pfx + '.3.weight']
+            self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.bias'], 'down4' if w.shape[-1] == 4 else 'same3', c)
+            c = w.shape[0]
+        res('mid_block1', c)
+        attn('mid_attn', c, False)
+        res('mid_block2', c)
+        for i in range(ns):
+            pfx = f'ups.{i}'
+            b1 = res(pfx + '.0', c, skip_c.pop())
+            c = b1.cout
+            b2 = res(pfx + '.1', c, skip_c.pop())
+            c = b2.cout
+            attn(pfx + '.2', c, True)
+            if (pfx + '.3.1.weight') in sd:
+                w = sd[pfx + '.3.1.weight']
+                self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.1.bias'], 'up3', c)
+            else:
+                w = sd[pfx + '.3.weight']
+                self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.bias'], 'same3', c)
+            c = w.shape[0]
+        res('final_res_block', c, self.init_dim)
+        self.mlp_names = [k for k in self.ss_off]          # creation order == offsets order
+        self.mlp_w = torch.cat([sd[k + '.mlp.1.weight'] for k in self.mlp_names], 0).contiguous()      # (total, emb)
+        self.mlp_b = torch.cat([sd[k + '.mlp.1.bias'] for k in self.mlp_names], 0).contiguous()
+        self.final_w = sd['final_conv.weight'].reshape(sd['final_conv.weight'].shape[0], -1).contiguous()   # (6, 64)
+
+    # ------------------------------------------------------------------ small dense layers
+    @staticmethod
+    def _lin(x, w, b):
+        return ops.linear(x, w.t().contiguous(), b)
+
+    def _embed_forward(self, time, classes, keep):
+        sd = self.sd
+        se = ops.sinusoidal_embed(time, self.freq)
+        h1 = self._lin(se, sd['time_mlp.1.weight'], sd['time_mlp.1.bias'])
+        a1 = ops.act(h1, 'gelu')
+        temb = self._lin(a1, sd['time_mlp.3.weight'], sd['time_mlp.3.bias'])
+        ce = ops.class_embed(classes, keep, sd['classes_emb.weight'], sd['null_classes_emb'])
+        h2 = self._lin(ce, sd['classes_mlp.0.weight'], sd['classes_mlp.0.bias'])
+        a2 = ops.act(h2, 'gelu')
+        cemb = self._lin(a2, sd['classes_mlp.2.weight'], sd['classes_mlp.2.bias'])
+        cond = torch.cat([temb, cemb], dim=1).contiguous()
+        ac = ops.act(cond, 'silu')
+        ss_all = self._lin(ac, self.mlp_w, self.mlp_b)
+        return ss_all, dict(se=se, h1=h1, a1=a1, ce=ce, h2=h2, a2=a2, cond=cond, ac=ac, classes=classes, keep=keep)
+
+    def _embed_backward(self, sv, dss_all, g):
+        sd = self.sd
+        dac, dw, db = ops.linear_backward(sv['ac'], self.mlp_w, dss_all)
+        off = 0
+        for k in self.mlp_names:
+            n2 = 2 * self.blocks[k].cout
+            g[k + '.mlp.1.weight'], g[k + '.mlp.1.bias'] = dw[off:off + n2].contiguous(), db[off:off + n2].contiguous()
+            off += n2
+        dcond = ops.act(sv['cond'], 'silu', dy=dac)
+        td = sd['time_mlp.3.weight'].shape[0]
+        dtemb, dcemb = dcond[:, :td].contiguous(), dcond[:, td:].contiguous()
+        da1, g['time_mlp.3.weight'], g['time_mlp.3.bias'] = ops.linear_backward(sv['a1'], sd['time_mlp.3.weight'], dtemb)
+        dh1 = ops.act(sv['h1'], 'gelu', dy=da1)
+        _, g['time_mlp.1.weight'], g['time_mlp.1.bias'] = ops.linear_backward(sv['se'], sd['time_mlp.1.weight'], dh1)
+        da2, g['classes_mlp.2.weight'], g['classes_mlp.2.bias'] = ops.linear_backward(sv['a2'], sd['classes_mlp.2.weight'], dcemb)
+        dh2 = ops.act(sv['h2'], 'gelu', dy=da2)
+        dce, g['classes_mlp.0.weight'], g['classes_mlp.0.bias'] = ops.linear_backward(sv['ce'], sd['classes_mlp.0.weight'], dh2)
+        tab = sd['classes_emb.weight']
+        dtab, dnull = torch.empty_like(tab), torch.empty_like(sd['null_classes_emb'])
+        ops.call('dmh_class_embed_backward', ops.ptr(dce), ops.ptr(sv['classes'], torch.int64), ops.ptr(sv['keep'], torch.uint8),
+                 ops.ptr(dtab), ops.ptr(dnull), dce.shape[0], dce.shape[1], tab.shape[0])
+        g['classes_emb.weight'], g['null_classes_emb'] = dtab, dnull
+
+    # ------------------------------------------------------------------ trunk
+    def forward(self, x, time, classes, rgb_flow, mask, keep, taps=None):
+        """x (B,6,H,W), rgb_flow (B,3,H,W), mask (B,1,H,W) NCHW fp32, time/classes (B,) int64, keep (B,) bool
+        -> out (B,6,H,W) NCHW, saved"""
+        B = x.shape[0]
+        keep = keep.to(torch.uint8).contiguous()
+        ss_all, emb = self._embed_forward(time, classes, keep)
+        xin = ops.assemble_input(x.contiguous(), rgb_flow.contiguous(), mask.contiguous(), cpad=self.cin_pad)
+        T = []                                                   # tape: (kind, block name, saved)
+
+        def ss(prefix):
+            o = self.ss_off[prefix]
+            return ss_all[:, o:o + 2 * self.blocks[prefix].cout]
+
+        def run_res(prefix, x0, x1=None):
+            out, sv = self.blocks[prefix].forward(x0, x1, ss(prefix))
+            T.append(('res', prefix, sv))
+            if taps is not None:
+                taps[prefix] = out
+            return out
+
+        def run_attn(prefix, x0):
+            out, sv = self.blocks[prefix].forward(x0)
+            T.append(('attn', prefix, sv))
+            if taps is not None:
+                taps[prefix] = out
+            return out
+
+        def run_conv(prefix, x0):
+            out, sv = self.blocks[prefix].forward(x0)
+            T.append(('conv', prefix, sv))
+            if taps is not None:
+                taps[prefix] = out
+            return out
+
+        h, _ = self.init.forward(xin)
+        if taps is not None:
+            taps['init_conv'] = h
+            taps['ss_all'] = ss_all
+        r = h
+        hs = []
+        for i in range(self.ns):
+            h = run_res(f'downs.{i}.0', h)
+            hs.append(h)
+            h = run_res(f'downs.{i}.1', h)
+            h = run_attn(f'downs.{i}.2', h)
+            hs.append(h)
+            h = run_conv(f'downs.{i}.3', h)
+        h = run_res('mid_block1', h)
+        h = run_attn('mid_attn', h)
+        h = run_res('mid_block2', h)
+        for i in range(self.ns):
+            h = run_res(f'ups.{i}.0', h, hs.pop())
+            h = run_res(f'ups.{i}.1', h, hs.pop())
+            h = run_attn(f'ups.{i}.2', h)
+            h = run_conv(f'ups.{i}.3', h)
+        h = run_res('final_res_block', h, r)
+        out = ops.final_conv_nchw(h, self.final_w, self.sd['final_conv.bias'])
+        return out, dict(tape=T, emb=emb, xin=xin, hfinal=h, B=B)
+
+    def backward(self, sv, dout):
+        """dout (B,6,H,W) NCHW -> {parameter name: gradient}"""
+        g = {}
+        sd, T = self.sd, sv['tape']
+        B = sv['B']
+        h = sv['hfinal']
+        _, H, W, cf = h.shape
+        hw = H * W
+        dout = dout.contiguous()
+        no = dout.shape[1]
+        # ---- final_conv (1x1, NCHW output): dh[p][c] = sum_o dout[o][p] w[o][c];  dw[o][c] = sum_{b,p} dout[o][p] h[p][c]
+        dh = torch.empty_like(h)
+        ops.bgemm(dout, (no * hw, 0, 1, hw), self.final_w, (0, 0, cf, 1), dh, (hw * cf, 0, cf, 1), hw, cf, no, B, 1)
+        dwb = ops._empty((B, no, cf), h)
+        ops.bgemm(dout, (no * hw, 0, hw, 1), h, (hw * cf, 0, cf, 1), dwb, (no * cf, 0, cf, 1), no, cf, hw, B, 1)
+        dw = ops._empty((no, cf), h)
+        ops.call('dmh_sum_over_batch', ops.ptr(dwb), ops.ptr(dw), B, no * cf)
+        g['final_conv.weight'] = dw.reshape(sd['final_conv.weight'].shape)
+        ones = torch.ones((hw, 1), device=h.device, dtype=torch.float32)
+        dbb = ops._empty((B, no), h)
+        ops.bgemm(dout, (no * hw, 0, hw, 1), ones, (0, 0, 1, 1), dbb, (no, 0, 1, 1), no, 1, hw, B, 1)
+        db = ops._empty((no,), h)
+        ops.call('dmh_sum_over_batch', ops.ptr(dbb), ops.ptr(db), B, no)
+        g['final_conv.bias'] = db
+        # ---- trunk, in reverse
+        dss_all = torch.zeros((B, self.ss_total), device=h.device, dtype=torch.float32)
+        names = {'w1': '.block1.proj.weight', 'b1': '.block1.proj.bias', 'g1': '.block1.norm.weight',
+                 'be1': '.block1.norm.bias', 'w2': '.block2.proj.weight', 'b2': '.block2.proj.bias',
+                 'g2': '.block2.norm.weight', 'be2': '.block2.norm.bias', 'rw': '.res_conv.weight', 'rb': '.res_conv.bias'}
+        idx = len(T)
+
+        def pop(kind):
+            nonlocal idx
+            idx -= 1
+            k, prefix, s = T[idx]
+            assert k == kind, (k, kind)
+            return prefix, s
+
+        def back_res(d):
+            prefix, s = pop('res')
+            blk = self.blocks[prefix]
+            dx, gg = blk.backward(s, d)
+            for k, v in gg.items():
+                if k == 'ss':
+                    o = self.ss_off[prefix]
+                    dss_all[:, o:o + 2 * blk.cout] = v
+                else:
+                    g[prefix + names[k]] = v.reshape(sd[prefix + names[k]].shape)
+            if blk.c1:
+                return dx[..., :blk.c0].contiguous(), dx[..., blk.c0:].contiguous()
+            return dx, None
+
+        def back_attn(d):
+            prefix, s = pop('attn')
+            a = self.blocks[prefix]
+            dx, gg = a.backward(s, d)
+            g[prefix + '.fn.norm.g'] = gg['g'].reshape(sd[prefix + '.fn.norm.g'].shape)
+            g[prefix + '.fn.fn.to_qkv.weight'] = gg['qkv']
+            if a.linear:
+                g[prefix + '.fn.fn.to_out.0.weight'], g[prefix + '.fn.fn.to_out.0.bias'] = gg['ow'], gg['ob']
+                g[prefix + '.fn.fn.to_out.1.g'] = gg['og'].reshape(sd[prefix + '.fn.fn.to_out.1.g'].shape)
+            else:
+                g[prefix + '.fn.fn.to_out.weight'], g[prefix + '.fn.fn.to_out.bias'] = gg['ow'], gg['ob']
+            return dx
+
+        def back_conv(d):
+            prefix, x0 = pop('conv')
+            cv = self.blocks[prefix]
+            dx, dw_, db_ = cv.backward(x0, d)
+            wname = prefix + ('.1.weight' if cv.kind == 'up3' else '.weight')
+            g[wname], g[wname.replace('weight', 'bias')] = dw_, db_
+            return dx
+
+        d, dr = back_res(dh)                                     # final_res_block: input cat(x, r)
+        skip_grads = []                                          # gradients of the skip tensors, in pop order
+        for i in reversed(range(self.ns)):
+            d = back_conv(d)
+            d = back_attn(d)
+            d, ds2 = back_res(d)                                 # ups.i.1: cat(x, hs.pop())
+            d, ds1 = back_res(d)                                 # ups.i.0
+            skip_grads.append((ds1, ds2))
+        d, _ = back_res(d)                                       # mid_block2
+        d = back_attn(d)
+        d, _ = back_res(d)                                       # mid_block1
+        # forward pushed [downs.0: a, b, downs.1: a, b, ...]; ups.0 popped downs.(ns-1).b then .a, ...
+        for i in reversed(range(self.ns)):
+            ds1, ds2 = skip_grads[i]      # appended for ups.(ns-1), ..., ups.0; ups.j pops the pushes of downs.(ns-1-j)
+            d = back_conv(d)                                     # downs.i.3
+            d = ops.add(d, ds1)                                  # downs.i.2's output was also pushed to the skip stack
+            d = back_attn(d)
+            d, _ = back_res(d)                                   # downs.i.1
+            d = ops.add(d, ds2)                                  # downs.i.0's output was pushed too
+            d, _ = back_res(d)                                   # downs.i.0
+        d = ops.add(d, dr)                                       # r = init_conv output, also fed to final_res_block
+        _, dw0, db0 = self.init.backward(sv['xin'], d, want_dx=False)
+        g['init_conv.weight'], g['init_conv.bias'] = dw0[:, :self.cin].contiguous(), db0
+        assert idx == 0
+        self._embed_backward(sv['emb'], dss_all, g)
+        return g

@@ -283,6 +283,27 @@ int dmh_bgemm(const float* A, const int64_t* sa, const float* B, const int64_t* 
 int dmh_softmax_rows(const float* S, float* P, int64_t rows, int n, void* stream);
 int dmh_softmax_rows_backward(const float* P, float* dP, int64_t rows, int n, void* stream);
 
+/* elementwise SiLU (mode 1) / exact GELU (mode 2): dy == NULL -> out = f(x), else out = dy * f'(x) */
+int dmh_act(const float* x, const float* dy, float* out, int64_t n, int mode, void* stream);
+/* backward of the class embedding lookup + null-class select (CFG:419-425): d [B][D] -> dtable [num_classes][D], dnull [D];
+ * keep: uint8 [B] (the mask drawn in the forward) */
+int dmh_class_embed_backward(const float* d, const int64_t* classes, const unsigned char* keep, float* dtable, float* dnull,
+                             int B, int D, int num_classes, void* stream);
+/* gradient of p_losses (CFG:796-806) wrt the UNet output: out, target [B][6][H][W]; warped = flow_warp(out[:,3:6], flow)
+ * [B][3][H][W]; mask [B][1][H][W]; abar [B] = alphas_cumprod[t]; squared: 0 L1, 1 L2.  dout [B][6][H][W]; gD [B][3][H][W]
+ * work.  The transpose of the bilinear gather uses float atomics (order not fixed where the flow field folds). */
+int dmh_loss_backward(const float* out, const float* target, const float* warped, const float* mask, const float* flow,
+                      const float* abar, float* dout, float* gD, int B, int H, int W, int squared, void* stream);
+/* optimiser (DDP:1852-1862): per-tensor partial sums of squares (f64 [dmh_sumsq_blocks()] each) -> global norm and clip
+ * coefficient (norm_out[0], norm_out[1] = min(1, max_norm / (norm + 1e-6))) -> Adam with the gradient scaled by
+ * gscale[1] (torch.optim.Adam, no weight decay) -> EMA lerp */
+int dmh_sumsq_blocks(void);
+int dmh_sumsq(const float* g, int64_t n, double* part, void* stream);
+int dmh_gradnorm_finalize(const double* part, int n, float max_norm, float* norm_out, void* stream);
+int dmh_adam(float* p, const float* g, float* m, float* v, const float* gscale, int64_t n, float lr, float b1, float b2,
+             float eps, int step, void* stream);
+int dmh_ema(float* ema, const float* p, int64_t n, float decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -206,3 +206,45 @@ def test_upsample_conv_backward(ops, C, Co, H, W):
     assert _rel('up dX', nchw(dx), gx) < 3e-6
     assert _rel('up dW', dw, gw) < 3e-6
     assert _rel('up db', db, gb) < 3e-6
+
+
+def test_unet_backward_vs_autograd():
+    """the whole conditional UNet (CFG:412-466), tiny geometry: forward with saved activations + backward on the HIP
+    kernels against torch autograd through the oracle's functional forward in fp64 — every parameter's gradient"""
+    from test_gpu_unet import make_cfg, _cond_inputs, g
+    from dmhomo_amd import train
+    from oracle import unet as OU
+    m, sd = make_cfg(8)
+    B, S = 3, 16
+    x, rf, mk = _cond_inputs(B, S, 700)
+    t = torch.tensor([17, 503, 998])
+    c = torch.zeros(B, dtype=torch.long)
+    keep = torch.tensor([True, False, True])
+    dout = rand((B, 6, S, S), 701)
+    # ---- reference
+    # (fp32 on purpose: the reference's weight standardisation switches to eps = 1e-3 for any other dtype, CFG:121)
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    out_ref = OU.cfg_unet_forward(sdd, x, t, c, rf, mk, keep)
+    pnames = [k for k, _ in m.named_parameters()]
+    grads = torch.autograd.grad(out_ref, [sdd[k] for k in pnames], dout, allow_unused=True)
+    ref = dict(zip(pnames, grads))
+    # ---- HIP
+    ut = train.UnetTrain(m)
+    out, saved = ut.forward(g(x), g(t), g(c), g(rf), g(mk), g(keep))
+    assert _rel('unet train fwd', out, out_ref.detach()) < 2e-4
+    got = ut.backward(saved, g(dout))
+    worst, missing = 0.0, [k for k in pnames if k not in got and ref[k] is not None]
+    assert not missing, missing
+    for k in pnames:
+        if ref[k] is None:
+            continue
+        if ref[k].abs().max() < 1e-4:            # e.g. a conv bias in front of a GroupNorm: its true gradient is 0
+            assert got[k].abs().max().item() < 1e-3, k
+            continue
+        r = ((got[k].double().cpu().reshape(ref[k].shape) - ref[k].double()).abs().max() /
+             ref[k].double().abs().max().clamp_min(1e-30)).item()
+        if r > 1e-4:
+            print(f'[parity] unet bwd {k}: rel_to_max={r:.3e} ref_absmax={ref[k].abs().max().item():.3e}')
+        worst = max(worst, r)
+    print(f'[parity] unet bwd: {len(pnames)} parameter gradients, worst rel_to_max={worst:.3e}')
+    assert worst < 2e-3, worst
