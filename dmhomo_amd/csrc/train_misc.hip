@@ -114,12 +114,21 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-// total = sum of part[0..n) (fixed order); norm_out[0] = sqrt(total), norm_out[1] = clip coefficient min(1, max_norm/(norm+1e-6))
-__global__ void gradnorm_finalize_kernel(const double* __restrict__ part, int n, float max_norm, float* __restrict__ norm_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// total = sum of part[0..n): thread t adds part[t], part[t+256], ... then a fixed tree -> the same value on every run;
+// norm_out[0] = sqrt(total), norm_out[1] = clip coefficient min(1, max_norm/(norm+1e-6))
+__global__ __launch_bounds__(256) void gradnorm_finalize_kernel(const double* __restrict__ part, int n, float max_norm,
+                                                                float* __restrict__ norm_out) {
+  __shared__ double red[256];
   double s = 0.0;
-  for (int i = 0; i < n; ++i) s += part[i];
-  const float nrm = (float)sqrt(s);
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const float nrm = (float)sqrt(red[0]);
   norm_out[0] = nrm;
   const float c = max_norm / (nrm + 1e-6f);
   norm_out[1] = c < 1.f ? c : 1.f;
@@ -186,7 +195,7 @@ extern "C" int dmh_sumsq(const float* g, int64_t n, double* part, void* stream) 
 }
 extern "C" int dmh_gradnorm_finalize(const double* part, int n, float max_norm, float* norm_out, void* stream) {
   DMH_REQUIRE(part && norm_out && n > 0, "dmh_gradnorm_finalize: bad arguments");
-  hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, n, max_norm, norm_out);
+  hipLaunchKernelGGL(gradnorm_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, n, max_norm, norm_out);
   DMH_CHECK_LAUNCH("dmh_gradnorm_finalize");
   return DMH_OK;
 }

@@ -244,28 +244,104 @@ def saveTrainPair(torch_tensor, mask, flows):
 # =====================================================================================
 # Trainer surface (DDP:1681-2021): constructor, save / load, sample
 # =====================================================================================
-class EMA(nn.Module):
-    """minimal stand-in for ema_pytorch.EMA holding the sampling copy (``ema_model``) with the same
-    state_dict prefixes (``ema_model.`` / ``online_model.`` + ``initted``, ``step``)."""
+def _clone_without_engine_caches(model):
+    """deepcopy of a module tree whose Unets get fresh (empty) kernel-program caches instead of copies"""
+    import copy
+    memo, engines = {}, []
+    for mod in model.modules():
+        eng = mod.__dict__.get('_engine')
+        if eng is not None:
+            memo[id(eng)] = None
+            engines.append(eng)
+    new = copy.deepcopy(model, memo)
+    it = iter(engines)
+    for mod in new.modules():
+        if '_engine' in mod.__dict__:
+            eng = next(it)
+            mod._engine = type(eng)(mod, groups=eng.groups)
+    return new
 
-    def __init__(self, model, beta=0.995, update_every=10):
+
+class EMA(nn.Module):
+    """stand-in for ema_pytorch.EMA (package not installed here; its published algorithm restated): holds the
+    sampling copy ``ema_model`` next to ``online_model`` with the same state_dict prefixes (``ema_model.`` /
+    ``online_model.`` + ``initted``, ``step``).  Until the first ``update()`` the two share weights (a sampling-only
+    run never pays for a second copy).  ``update()`` follows ema_pytorch: every ``update_every`` calls; copy while
+    step <= update_after_step, afterwards ema <- lerp(ema, online, 1 - decay) with
+    decay = clamp(1 - (1 + (step - update_after_step - 1) / inv_gamma) ** -power, min_value, beta)."""
+
+    def __init__(self, model, beta=0.995, update_every=10, update_after_step=100, inv_gamma=1.0, power=2 / 3,
+                 min_value=0.0):
         super().__init__()
         self.online_model = model
         self.ema_model = model            # sampling reads ema_model (DDP:1960); weights are shared until trained
         self.beta, self.update_every = beta, update_every
-        self.register_buffer('initted', torch.tensor(True))
+        self.update_after_step, self.inv_gamma, self.power, self.min_value = update_after_step, inv_gamma, power, min_value
+        self.register_buffer('initted', torch.tensor(False))
         self.register_buffer('step', torch.tensor(0))
 
+    def _own_copy(self):
+        if self.ema_model is self.online_model:
+            self.ema_model = _clone_without_engine_caches(self.online_model)
+            self.ema_model.requires_grad_(False)
+
+    def get_current_decay(self):
+        epoch = max(int(self.step.item()) - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.
+        value = 1 - (1 + epoch / self.inv_gamma) ** -self.power
+        return min(max(value, self.min_value), self.beta)
+
+    def _pairs(self):
+        on = dict(self.online_model.named_parameters())
+        return [(p, on[k]) for k, p in self.ema_model.named_parameters()]
+
+    def _bump(self):
+        for mod in self.ema_model.modules():
+            if '_engine' in mod.__dict__:
+                mod._dmh_epoch = getattr(mod, '_dmh_epoch', 0) + 1
+
+    def copy_params_from_model_to_ema(self):
+        from . import ops
+        for pe, po in self._pairs():
+            ops.ema_(pe.data, po.data, 0.)
+        self._bump()
+
+    def update(self):
+        from . import ops
+        self._own_copy()
+        step = int(self.step.item())
+        self.step += 1
+        if step % self.update_every != 0:
+            return
+        if step <= self.update_after_step:
+            self.copy_params_from_model_to_ema()
+            return
+        if not bool(self.initted.item()):
+            self.copy_params_from_model_to_ema()
+            self.initted.fill_(True)
+        decay = self.get_current_decay()
+        for pe, po in self._pairs():
+            ops.ema_(pe.data, po.data, decay)
+        self._bump()
+
     def state_dict(self, *a, **k):
-        sd = self.online_model.state_dict()
         out = {'initted': self.initted, 'step': self.step}
-        for key, v in sd.items():
+        for key, v in self.online_model.state_dict().items():
             out['online_model.' + key] = v
+        for key, v in self.ema_model.state_dict().items():
             out['ema_model.' + key] = v
         return out
 
     def load_state_dict(self, sd, strict=True):
         ema = {k[len('ema_model.'):]: v for k, v in sd.items() if k.startswith('ema_model.')}
+        online = {k[len('online_model.'):]: v for k, v in sd.items() if k.startswith('online_model.')}
+        if online and any(not torch.equal(ema[k].cpu(), v.cpu()) for k, v in online.items() if k in ema):
+            self._own_copy()              # a checkpoint from a trained run: the two copies differ
+        if 'step' in sd:
+            self.step.fill_(int(sd['step']))
+        if 'initted' in sd:
+            self.initted.fill_(bool(sd['initted']))
         return self.ema_model.load_state_dict(ema, strict=strict)
 
 
@@ -328,11 +404,15 @@ class Trainer(object):
         self.ema = EMA(diffusion_model, beta=ema_decay, update_every=ema_update_every)
         self.results_folder = Path(results_folder)
         self.step = 0
+        self.train_lr, self.adam_betas = train_lr, adam_betas
+        self._ts = None                   # train.TrainStep (Adam moments, packed training weights), built on first use
+        self._opt_state = None            # an optimiser state_dict loaded before the first training step
 
     def save(self, milestone):
         self.results_folder.mkdir(exist_ok=True)
-        data = {'step': self.step, 'model': self.model.state_dict(), 'opt': None, 'ema': self.ema.state_dict(),
-                'scaler': None, 'version': __version__}
+        data = {'step': self.step, 'model': self.model.state_dict(),
+                'opt': self._ts.state_dict() if self._ts is not None else self._opt_state,
+                'ema': self.ema.state_dict(), 'scaler': None, 'version': __version__}
         torch.save(data, str(self.results_folder / f'model-{milestone}.pt'))
 
     def load(self, milestone):
@@ -342,11 +422,50 @@ class Trainer(object):
         self.step = data['step']
         if data.get('ema') is not None:
             self.ema.load_state_dict(data['ema'], strict=False)
+        if data.get('opt') is not None:
+            self._opt_state = data['opt']
+            if self._ts is not None:
+                self._ts.load_state_dict(self._opt_state)
+        if self._ts is not None:
+            self._ts.ut.refresh()
         if 'version' in data:
             print(f"loading from version {data['version']}")
 
-    def train(self):
-        raise NotImplementedError('Trainer.train (backward kernels + RCCL all-reduce) is SURVEY.md §8f "next" row 1')
+    def train_step_engine(self):
+        if self._ts is None:
+            from .train import TrainStep
+            self._ts = TrainStep(self.model, lr=self.train_lr, betas=self.adam_betas,
+                                 accum=self.gradient_accumulate_every)
+            if self._opt_state is not None:
+                self._ts.load_state_dict(self._opt_state)
+        return self._ts
+
+    def train(self, log=None):
+        """DDP:1828-1940: gradient accumulation, clip_grad_norm_(1.0), Adam, EMA, checkpoints (the latest as 9999 every
+        500 steps, numbered ones every ``save_and_sample_every``).  The PNG/GIF sample dumps of DDP:1871-1935 are
+        visualisation and stay out.  Ranks > 0 of a torch.distributed run train in lock-step (gradients averaged by
+        one RCCL all-reduce per step) and leave EMA / checkpoints to rank 0, like accelerate's main process."""
+        import torch.distributed as dist
+        ts = self.train_step_engine()
+        dev = next(self.model.parameters()).device
+        main = not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+        while self.step < self.train_num_steps:
+            batches = []
+            for _ in range(self.gradient_accumulate_every):
+                data = next(self.dl)
+                batches.append((data[0].to(dev), data[1].to(dev)))
+            total_loss = ts.step(batches)
+            self.step += 1
+            if log is not None:
+                log(self.step, total_loss)
+            if main:
+                self.ema.update()
+                if self.step % 500 == 0:
+                    self.save(9999)
+                if self.step % self.save_and_sample_every == 0:
+                    self.save(self.step // self.save_and_sample_every)
+        if main:
+            print('training complete')
 
     def sample(self, idx, rank, step=1):
         """DDP:1941-2021 without the every-100-steps PNG/GIF dumps (visualisation is out of scope)."""

@@ -47,7 +47,8 @@ class UnetEngine:
 
     # ------------------------------------------------------------------ weights
     def _signature(self):
-        return tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        # _dmh_epoch: bumped by train.TrainStep, whose kernels update the weights behind torch's version counters
+        return (getattr(self.module, '_dmh_epoch', 0),) + tuple((p.data_ptr(), p._version) for p in self.module.parameters())
 
     def ensure_prepared(self):
         sig = self._signature()

@@ -576,3 +576,42 @@ def linear_backward(x, w, dy, want_bias=True):
         db = _empty((cout,), x)
         call('dmh_sum_over_batch', ptr(dy), ptr(db), Bn, cout)
     return dx, dw, db
+
+
+# ------------------------------------------------------------------ loss gradient + optimiser (training step)
+def loss_backward(out, target, warped, mask, flow, abar, squared=False):
+    """gradient of p_losses (CFG:796-806) wrt the UNet output (B,6,H,W); ``warped`` = flow_warp(out[:, 3:], flow)."""
+    B, _, H, W = out.shape
+    dout = torch.empty_like(out)
+    gD = torch.empty((B, 3, H, W), device=out.device, dtype=F32)
+    call('dmh_loss_backward', ptr(out), ptr(target.contiguous()), ptr(warped), ptr(mask.contiguous()),
+         ptr(flow.contiguous()), ptr(abar.contiguous()), ptr(dout), ptr(gD), B, H, W, int(bool(squared)))
+    return dout
+
+
+def sumsq_blocks():
+    return int(lib().dmh_sumsq_blocks())
+
+
+def grad_norm_clip(grads, max_norm):
+    """torch.nn.utils.clip_grad_norm_ (DDP:1852) as data: (2,) tensor [total L2 norm, min(1, max_norm/(norm+1e-6))];
+    the gradients themselves are left alone — dmh_adam multiplies by the coefficient while reading them."""
+    nb = sumsq_blocks()
+    dev = grads[0].device
+    part = torch.empty((len(grads) * nb,), device=dev, dtype=torch.float64)
+    for i, gr in enumerate(grads):
+        call('dmh_sumsq', ptr(gr), gr.numel(), ptr(part[i * nb:], torch.float64))
+    out = torch.empty((2,), device=dev, dtype=F32)
+    call('dmh_gradnorm_finalize', ptr(part, torch.float64), part.numel(), float(max_norm), ptr(out))
+    return out
+
+
+def adam_(p, g, m, v, gscale, lr, b1, b2, eps, step):
+    """in-place torch.optim.Adam update (no weight decay, no amsgrad) of p with gradient g * gscale[1]."""
+    call('dmh_adam', ptr(p), ptr(g), ptr(m), ptr(v), ptr(gscale), p.numel(), float(lr), float(b1), float(b2),
+         float(eps), int(step))
+
+
+def ema_(ema, p, decay):
+    """ema <- ema * decay + p * (1 - decay), in place."""
+    call('dmh_ema', ptr(ema), ptr(p), p.numel(), float(decay))

@@ -1,4 +1,4 @@
-"""Training pieces built so far (SURVEY.md §8f "next" row 1 — IN PROGRESS, not a training loop yet).
+"""Training step of the DGM diffusion model on the HIP kernels (SURVEY.md §8f "next" row 1).
 
 ``ResnetBlockTrain`` runs the forward of one ResnetBlock (CFG:216-241) on the same kernels as sampling while saving what
 the backward pass needs, and the backward pass itself on the HIP kernels of csrc/conv_backward.hip and
@@ -10,8 +10,10 @@ csrc/norm_backward.hip:
   backward  GN+SiLU backward (3 kernels) -> conv weight / bias gradient (fp32 MFMA, pixels as the K axis) -> weight
             standardisation backward -> data gradient = the forward conv kernel with the flipped, transposed weight
 
-Still missing for a training step: the same for attention / LayerNorm / embeddings / up- and down-sampling convs, the loss
-gradient (incl. grid_sample wrt its input), Adam + EMA, gradient all-reduce.  ``Trainer.train`` keeps raising.
+``UnetTrain`` strings those blocks, the attention / LayerNorm / embedding / resampling-conv backward kernels into the
+whole conditional UNet (CFG:412-466) with a manual tape; ``TrainStep`` adds p_losses (CFG:770-806) with its gradient,
+gradient accumulation, the global-norm clip, Adam and the RCCL gradient all-reduce: one optimiser step of
+``Trainer.train`` (DDP:1830-1862).  There is no autograd anywhere on this path.
 """
 import torch
 
@@ -441,3 +443,136 @@ class UnetTrain:
         assert idx == 0
         self._embed_backward(sv['emb'], dss_all, g)
         return g
+
+
+class TrainStep:
+    """one optimiser step of the reference's training loop (DDP:1830-1862) for a dmhomo_amd.cfg.GaussianDiffusion:
+
+        for _ in range(accum):  loss = diffusion(batch, classes=...) / accum;  loss.backward()      DDP:1839-1850
+        clip_grad_norm_(parameters, 1.0);  opt.step();  opt.zero_grad()                             DDP:1852-1862
+
+    with torch.optim.Adam(lr, betas) semantics (DDP:1741).  Gradients of ranks > 1 are averaged with one RCCL
+    all-reduce over a flat buffer (what accelerate's DDP wrapper does for the reference)."""
+
+    def __init__(self, diffusion, lr=1e-4, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=1.0, accum=1, groups=8):
+        self.diffusion, self.unet = diffusion, diffusion.model
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.max_grad_norm, self.accum = max_grad_norm, accum
+        self.params = dict(self.unet.named_parameters())
+        for k, p in self.params.items():
+            assert p.dtype == torch.float32 and p.is_contiguous(), k
+        self.ut = UnetTrain(self.unet, groups)
+        self.m = {k: torch.zeros_like(p) for k, p in self.params.items()}
+        self.v = {k: torch.zeros_like(p) for k, p in self.params.items()}
+        self.opt_step = 0
+        self.last_norm = None
+
+    # ---- forward + backward of GaussianDiffusion.forward (CFG:808-842) on one 12-channel batch
+    def loss_and_grads(self, img, classes, t=None, noise=None, keep=None, grad_scale=1.0):
+        """-> (loss (0-dim tensor, unscaled), {parameter name: d(grad_scale * loss)/d parameter}).  ``t``, ``noise``,
+        ``keep`` default to the reference's draws, in its order (CFG:812 randint, CFG:773 randn_like, CFG:422 uniform)."""
+        from .ddpm import flow_warp
+        df = self.diffusion
+        b, c, h, w = img.shape
+        assert h == df.image_size and w == df.image_size, f'height and width of image must be {df.image_size}'
+        dev = img.device
+        if t is None:
+            t = torch.randint(0, df.num_timesteps, (b,), device=dev).long()
+        x_start = ops.affine(img[:, :6].to(torch.float32), 2., -1.)
+        mask = img[:, 6:7].to(torch.float32).contiguous()
+        rgb_flow = ops.affine(img[:, -5:-2].to(torch.float32), 2., -1.)
+        flow = img[:, -2:].to(torch.float32).contiguous()
+        if noise is None:
+            noise = df.rng.randn(x_start.shape, dev)
+        noise = noise.to(torch.float32).contiguous()
+        t = t.to(torch.int64).contiguous()
+        if keep is None:
+            keep = self.unet._keep_mask(b, self.unet.cond_drop_prob, dev)
+            if keep is None:
+                keep = torch.ones((b,), device=dev, dtype=torch.uint8)
+        squared = df.loss_fn == 'l2'
+        x = df.q_sample(x_start, t, noise)
+        out, saved = self.ut.forward(x, t, classes.to(torch.int64).contiguous(), rgb_flow, mask, keep)
+        warped = flow_warp(out[:, 3:].contiguous(), flow)
+        if df.objective == 'pred_noise':
+            target = noise
+        elif df.objective == 'pred_x0':
+            target = x_start
+        elif df.objective == 'pred_v':
+            ca = df.sqrt_alphas_cumprod.gather(-1, t).contiguous()
+            cb = (-df.sqrt_one_minus_alphas_cumprod).gather(-1, t).contiguous()
+            target = ops.q_sample(noise, x_start, ca, cb)
+        else:
+            raise ValueError(f'unknown objective {df.objective}')
+        abar = df.alphas_cumprod.gather(-1, t).to(torch.float32).contiguous()
+        loss = ops.loss_combine(ops.diff_mean(out, target, None, squared),
+                                ops.diff_mean(warped, out[:, :3].contiguous(), mask, squared), abar)
+        dout = ops.loss_backward(out, target, warped, mask, flow, abar, squared)
+        if grad_scale != 1.0:
+            dout = ops.affine(dout, grad_scale, 0.)
+        return loss, self.ut.backward(saved, dout)
+
+    # ---- torch.optim.Adam.state_dict() layout, parameters in diffusion.parameters() order (DDP:1741, 1793)
+    def state_dict(self):
+        names = list(self.params)
+        state = {}
+        if self.opt_step > 0:
+            for i, k in enumerate(names):
+                state[i] = {'step': torch.tensor(float(self.opt_step)), 'exp_avg': self.m[k], 'exp_avg_sq': self.v[k]}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': 0, 'amsgrad': False,
+                 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                 'params': list(range(len(names)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        names = list(self.params)
+        for i, st in sd.get('state', {}).items():
+            k = names[int(i)]
+            self.m[k].copy_(st['exp_avg'])
+            self.v[k].copy_(st['exp_avg_sq'])
+            self.opt_step = int(float(st['step']))
+        for grp in sd.get('param_groups', [])[:1]:
+            self.lr, self.betas, self.eps = grp['lr'], tuple(grp['betas']), grp['eps']
+
+    def _allreduce_mean(self, grads):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return grads
+        names = list(grads)
+        flat = torch.cat([grads[k].reshape(-1) for k in names])           # one bucket: ~36M floats for the DGM UNet
+        dist.all_reduce(flat)
+        flat = ops.affine(flat, 1.0 / dist.get_world_size(), 0.)
+        out, o = {}, 0
+        for k in names:
+            n = grads[k].numel()
+            out[k] = flat[o:o + n].view(grads[k].shape)
+            o += n
+        return out
+
+    def apply(self, grads):
+        """clip by global norm, Adam, bump the weight epoch (the sampling engine and UnetTrain re-pack on it)."""
+        names = [k for k in self.params if k in grads]
+        gl = [grads[k].contiguous() for k in names]
+        clip = ops.grad_norm_clip(gl, self.max_grad_norm)
+        self.opt_step += 1
+        for k, gr in zip(names, gl):
+            ops.adam_(self.params[k].data, gr, self.m[k], self.v[k], clip, self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.opt_step)
+        self.unet._dmh_epoch = getattr(self.unet, '_dmh_epoch', 0) + 1
+        self.ut.refresh()
+        self.last_norm = clip
+        return clip
+
+    def step(self, batches, draws=None):
+        """``batches``: ``accum`` pairs (12-channel batch, classes).  -> summed (loss / accum) like DDP:1849."""
+        assert len(batches) == self.accum
+        total, acc = None, None
+        for i, (img, classes) in enumerate(batches):
+            kw = draws[i] if draws is not None else {}
+            loss, gr = self.loss_and_grads(img, classes, grad_scale=1.0 / self.accum, **kw)
+            acc = gr if acc is None else {k: ops.add(acc[k], gr[k]) for k in acc}
+            part = loss / self.accum
+            total = part if total is None else total + part
+        acc = self._allreduce_mean(acc)
+        self.apply(acc)
+        return total

@@ -248,3 +248,162 @@ def test_unet_backward_vs_autograd():
         worst = max(worst, r)
     print(f'[parity] unet bwd: {len(pnames)} parameter gradients, worst rel_to_max={worst:.3e}')
     assert worst < 2e-3, worst
+
+
+# ----------------------------------------------------------------------------------------------- training step
+def _ref_flow_warp(x, flow):
+    """the reference's flow_warp (DDP:1262-1280) as the torch op it calls: grid_sample, bilinear, border, align_corners"""
+    B, _, H, W = x.shape
+    xs = torch.arange(W, dtype=x.dtype).view(1, 1, W).expand(B, H, W)
+    ys = torch.arange(H, dtype=x.dtype).view(1, H, 1).expand(B, H, W)
+    gx = 2.0 * (xs + flow[:, 0]) / (W - 1) - 1.0
+    gy = 2.0 * (ys + flow[:, 1]) / (H - 1) - 1.0
+    return F.grid_sample(x, torch.stack([gx, gy], -1), mode='bilinear', padding_mode='border', align_corners=True)
+
+
+@pytest.mark.parametrize('squared', [False, True], ids=['l1', 'l2'])
+def test_loss_backward_vs_autograd(ops, squared):
+    """gradient of p_losses (CFG:796-806) wrt the UNet output, incl. the transpose of grid_sample; flows leave the
+    image on every side (border clamp) and fold over themselves"""
+    B, H, W = 3, 24, 40
+    out = rand((B, 6, H, W), 800)
+    target = rand((B, 6, H, W), 801)
+    mask = (torch.rand((B, 1, H, W), generator=torch.Generator().manual_seed(802)) > 0.4).float()
+    flow = rand((B, 2, H, W), 803, 6.0)
+    abar = torch.tensor([0.9, 0.31, 0.004])
+    od = out.double().requires_grad_(True)
+    fn = F.mse_loss if squared else F.l1_loss
+    warped_ref = _ref_flow_warp(od[:, 3:], flow.double())
+    loss = fn(od, target.double(), reduction='none').reshape(B, -1).mean() + \
+        (abar.double()[:, None] * (mask.double() * fn(warped_ref, od[:, :3], reduction='none')).reshape(B, -1)).mean()
+    gref, = torch.autograd.grad(loss, od)
+    o = out.to(dev())
+    warped = ops.flow_warp(o[:, 3:].contiguous(), flow.to(dev()))
+    got = ops.loss_backward(o, target.to(dev()), warped, mask.to(dev()), flow.to(dev()), abar.to(dev()), squared)
+    assert _rel('loss backward', got, gref) < 5e-6
+
+
+def test_adam_clip_ema_vs_torch(ops):
+    """dmh_sumsq / dmh_gradnorm_finalize / dmh_adam / dmh_ema against clip_grad_norm_ + torch.optim.Adam + lerp_"""
+    shapes = [(64, 64, 3, 3), (257,), (1, 8, 1, 1), (33, 129)]
+    ps = [rand(s, 810 + i) for i, s in enumerate(shapes)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.99))
+    mine = [p.clone().to(dev()) for p in ps]
+    m = [torch.zeros_like(p) for p in mine]
+    v = [torch.zeros_like(p) for p in mine]
+    ema_ref = [p.clone() for p in ps]
+    ema = [p.clone().to(dev()) for p in ps]
+    for step in range(1, 5):
+        gs = [rand(s, 820 + 10 * step + i, 0.02 * step) for i, s in enumerate(shapes)]
+        for r, gr in zip(ref, gs):
+            r.grad = gr.clone()
+        nrm = torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        opt.step()
+        clip = ops.grad_norm_clip([gr.to(dev()) for gr in gs], 1.0)
+        assert abs(clip[0].item() - nrm.item()) <= 1e-6 * nrm.item()
+        for p_, gr, m_, v_ in zip(mine, gs, m, v):
+            ops.adam_(p_, gr.to(dev()), m_, v_, clip, 1e-3, 0.9, 0.99, 1e-8, step)
+        for e_, er, p_, r in zip(ema, ema_ref, mine, ref):
+            ops.ema_(e_, p_, 0.9)
+            er.lerp_(r.detach(), 1 - 0.9)
+    for i, (p_, r) in enumerate(zip(mine, ref)):
+        d = (p_.cpu() - r.detach()).abs().max().item()
+        print(f'[parity] adam tensor {i}: max abs diff {d:.3e} after 4 steps of ~1e-3')
+        assert d < 5e-7                           # parameters reach |4|: one fp32 ulp there is 4.8e-7
+        assert (ema[i].cpu() - ema_ref[i]).abs().max().item() < 5e-7
+
+
+def _train_setup(golden_dir, lr=1e-3, accum=1):
+    import numpy as np
+    import os
+    from test_gpu_unet import make_cfg, g
+    from dmhomo_amd import cfg, train
+    gd = {k: v for k, v in np.load(os.path.join(golden_dir, 'train_step.npz')).items()}
+    m, sd = make_cfg(8)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=4, objective='pred_x0',
+                              loss_type='l1').to(dev())
+    ts = train.TrainStep(d, lr=lr, betas=(0.9, 0.99), accum=accum)
+    T = lambda k: torch.from_numpy(gd[k])
+    draws = dict(t=g(T('t')), noise=g(T('noise')), keep=g(T('keep')))
+    return gd, m, d, ts, g(T('img12')), g(T('classes')), draws
+
+
+def test_train_step_gradients_vs_reference(golden_dir):
+    """the reference's own loss.backward() (tests/golden/make_golden_train.py): loss, every parameter gradient, and the
+    global norm clip_grad_norm_ reports"""
+    gd, m, d, ts, img, classes, draws = _train_setup(golden_dir)
+    loss, grads = ts.loss_and_grads(img, classes, **draws)
+    want = float(gd['loss'])
+    print(f'[parity] train loss: got {float(loss):.7f} want {want:.7f}')
+    assert abs(float(loss) - want) <= 2e-5 * abs(want)
+    worst = 0.0
+    for k, _ in m.named_parameters():
+        ref = torch.from_numpy(gd['grad.' + k]).double()
+        got = grads[k].double().cpu().reshape(ref.shape)
+        if ref.abs().max() < 1e-5:                # conv biases in front of a GroupNorm: true gradient 0
+            assert got.abs().max().item() < 1e-4, k
+            continue
+        r = ((got - ref).abs().max() / ref.abs().max()).item()
+        if r > 1e-4:
+            print(f'[parity] train grad {k}: rel_to_max={r:.3e}')
+        worst = max(worst, r)
+    clip = ts.apply(grads)
+    print(f'[parity] train step: worst gradient rel_to_max={worst:.3e}; grad norm {clip[0].item():.6f} '
+          f'want {float(gd["grad_norm"]):.6f}')
+    assert worst < 1e-3
+    assert abs(clip[0].item() - float(gd['grad_norm'])) <= 1e-4 * float(gd['grad_norm'])
+
+
+def test_train_trajectory_vs_reference(golden_dir):
+    """6 optimiser steps of DDP:1840-1858 (accumulate 2, clip 1.0, Adam lr 1e-3) on a fixed batch with fixed draws: the
+    loss the reference's own loop printed at each step, and the parameter norm after it"""
+    gd, m, d, ts, img, classes, draws = _train_setup(golden_dir, lr=1e-3, accum=2)
+    for i in range(6):
+        total = ts.step([(img, classes), (img, classes)], draws=[draws, draws])
+        pl2 = float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in m.parameters())))
+        want, wl2 = float(gd['traj.loss'][i]), float(gd['traj.param_l2'][i])
+        print(f'[parity] train step {i}: loss {float(total):.6f} want {want:.6f}   |params| {pl2:.6f} want {wl2:.6f}')
+        assert abs(float(total) - want) <= (1e-5 if i == 0 else 1e-4) * want
+        assert abs(pl2 - wl2) <= 1e-4 * wl2
+    # the sampling engine sees the trained weights (its packed copies are rebuilt on the weight epoch)
+    out = m(draws['noise'], draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(), cond_drop_prob=0.)
+    out2, _ = ts.ut.forward(draws['noise'], draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(),
+                            torch.ones(3, dtype=torch.uint8, device=img.device))
+    assert (out - out2).abs().max().item() < 2e-4 * out2.abs().max().item()
+
+
+def test_trainer_train_loop_and_checkpoint(golden_dir, tmp_path):
+    """Trainer.train (DDP:1828-1940): steps, EMA schedule, checkpoint with optimiser state, resume"""
+    from test_gpu_unet import make_cfg
+    from dmhomo_amd import cfg, ddpm
+    m, _ = make_cfg(8)
+    d = cfg.GaussianDiffusion(m, image_size=32, timesteps=1000, sampling_timesteps=2, objective='pred_x0').to(dev())
+    w0 = m.init_conv.weight.detach().clone()
+    tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=2, gradient_accumulate_every=2, train_lr=1e-3,
+                      train_num_steps=4, results_folder=str(tmp_path), save_and_sample_every=4, ema_update_every=1)
+    tr.ema.update_after_step = 1
+    losses = []
+    tr.train(log=lambda s, l: losses.append(float(l)))
+    assert tr.step == 4 and len(losses) == 4 and all(l == l for l in losses)
+    assert not torch.equal(w0, m.init_conv.weight.detach())
+    assert tr.ema.ema_model is not tr.ema.online_model and int(tr.ema.step) == 4
+    ck = torch.load(str(tmp_path / 'model-1.pt'), map_location='cpu')
+    assert set(ck) == {'step', 'model', 'opt', 'ema', 'scaler', 'version'} and ck['step'] == 4
+    assert len(ck['opt']['state']) == len(list(d.parameters())) and ck['opt']['param_groups'][0]['lr'] == 1e-3
+    ref = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in d.parameters()], lr=1.0)
+    ref.load_state_dict(ck['opt'])                      # the layout torch.optim.Adam itself accepts
+    # EMA with update_after_step = 1: copies on updates 1-3, a lerp with decay 1 - 3^(-2/3) on the 4th
+    e, o = tr.ema.ema_model.model.init_conv.weight, m.init_conv.weight
+    assert not torch.equal(e.detach(), o.detach())
+    m2, _ = make_cfg(8, seed=5)
+    d2 = cfg.GaussianDiffusion(m2, image_size=32, timesteps=1000, sampling_timesteps=2, objective='pred_x0').to(dev())
+    tr2 = ddpm.Trainer(d2, 'DGM_Conditions', train_batch_size=2, gradient_accumulate_every=2, train_lr=1e-3,
+                       train_num_steps=5, results_folder=str(tmp_path))
+    tr2.load(1)
+    assert tr2.step == 4 and torch.equal(m2.init_conv.weight.detach(), m.init_conv.weight.detach())
+    assert torch.equal(tr2.ema.ema_model.model.init_conv.weight.detach(), e.detach())
+    ts2 = tr2.train_step_engine()
+    assert ts2.opt_step == 4 and torch.equal(ts2.m['init_conv.weight'], tr.train_step_engine().m['init_conv.weight'])
+    tr2.train()
+    assert tr2.step == 5
