@@ -154,12 +154,18 @@ __global__ __launch_bounds__(256, NCB == 4 ? 2 : 1) void conv_wgrad_kernel(WgArg
   }
 }
 
-// dW[o][c][tap] (OIHW, Cin = C0 + C1) = sum over the splits, in split order; same for db
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part_w, const float* __restrict__ part_b,
-                                         float* __restrict__ dw, float* __restrict__ db, int Cout, int Cin, int NT,
-                                         int nsplit, int otiles, int ctiles, int cw) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// dW[o][c][tap] (OIHW, Cin = C0 + C1) = sum over the pixel splits; same for db.  A workgroup owns 64 consecutive outputs
+// (one 256-byte row of every partial block: coalesced) and spreads the splits over its 4 waves: wave g adds splits
+// g, g+4, ... in order, then the four sums are combined as (s0 + s1) + (s2 + s3) — a fixed tree, the same bits every run.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part_w,
+                                                                const float* __restrict__ part_b, float* __restrict__ dw,
+                                                                float* __restrict__ db, int Cout, int Cin, int NT,
+                                                                int nsplit, int otiles, int ctiles, int cw) {
+  __shared__ float red[4][64];
+  const int j = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + j;
   const int64_t total = (int64_t)Cout * Cin * NT;
+  float s = 0.f;
   if (idx < total) {
     const int t = idx % NT;
     const int c = (idx / NT) % Cin;
@@ -167,19 +173,31 @@ __global__ void conv_wgrad_reduce_kernel(const float* __restrict__ part_w, const
     const int pair = (o / 64) * ctiles + c / cw;  // cw input channels per workgroup block (64, or 16 for the 7x7 conv)
     const size_t off = ((size_t)pair * 64 * 64 + (size_t)(o % 64) * 64 + c % cw) * NT + t;
     const size_t stride = (size_t)otiles * ctiles * 64 * 64 * NT;
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += part_w[sp * stride + off];
-    dw[idx] = s;
+    const float* src = part_w + off;
+    int sp = g;
+    for (; sp + 12 < nsplit; sp += 16) {  // four loads in flight
+      const float v0 = src[(size_t)sp * stride], v1 = src[(size_t)(sp + 4) * stride];
+      const float v2 = src[(size_t)(sp + 8) * stride], v3 = src[(size_t)(sp + 12) * stride];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; sp < nsplit; sp += 4) s += src[(size_t)sp * stride];
   }
-  if (db && idx < Cout) {
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += part_b[((size_t)sp * otiles + idx / 64) * 64 + idx % 64];
-    db[idx] = s;
+  red[g][j] = s;
+  __syncthreads();
+  if (g == 0 && idx < total) dw[idx] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  if (db && blockIdx.x == 0) {
+    for (int o = threadIdx.x; o < Cout; o += 256) {
+      float sb = 0.f;
+      for (int sp = 0; sp < nsplit; ++sp) sb += part_b[((size_t)sp * otiles + o / 64) * 64 + o % 64];
+      db[o] = sb;
+    }
   }
 }
 
+// pixel splits: about 512 workgroups per launch (2 per CU, the kernel's occupancy): every extra split costs a 64x64xtaps
+// partial block written and read back
 static int wgrad_splits(int nitems, int npairs) {
-  int s = 1024 / (npairs > 0 ? npairs : 1);
+  int s = 512 / (npairs > 0 ? npairs : 1);
   if (s < 1) s = 1;
   if (s > nitems) s = nitems;
   return s;
@@ -253,7 +271,7 @@ extern "C" int dmh_conv_wgrad(const float* dy, const float* src0, const float* s
   }
   DMH_CHECK_LAUNCH("dmh_conv_wgrad");
   const int64_t total = (int64_t)Cout * (a.C0 + a.C1) * KH * KH;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)cdiv64(total > Cout ? total : Cout, 256)), dim3(256), 0, st,
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 64)), dim3(256), 0, st,
                      a.part_w, a.part_b, dw, db, Cout, a.C0 + a.C1, KH * KH, a.nsplit, otiles, a.ctiles, cw);
   DMH_CHECK_LAUNCH("dmh_conv_wgrad(reduce)");
   return DMH_OK;

@@ -357,16 +357,20 @@ class UnetTrain:
         # ---- final_conv (1x1, NCHW output): dh[p][c] = sum_o dout[o][p] w[o][c];  dw[o][c] = sum_{b,p} dout[o][p] h[p][c]
         dh = torch.empty_like(h)
         ops.bgemm(dout, (no * hw, 0, 1, hw), self.final_w, (0, 0, cf, 1), dh, (hw * cf, 0, cf, 1), hw, cf, no, B, 1)
-        dwb = ops._empty((B, no, cf), h)
-        ops.bgemm(dout, (no * hw, 0, hw, 1), h, (hw * cf, 0, cf, 1), dwb, (no * cf, 0, cf, 1), no, cf, hw, B, 1)
+        # (the pixel axis is the K of these two: split it over the inner batch index so the launch has waves to spare)
+        ks = 256 if hw % 256 == 0 else hw
+        nk = hw // ks
+        dwb = ops._empty((B, nk, no, cf), h)
+        ops.bgemm(dout, (no * hw, ks, hw, 1), h, (hw * cf, ks * cf, cf, 1), dwb, (nk * no * cf, no * cf, cf, 1), no, cf, ks,
+                  B, nk)
         dw = ops._empty((no, cf), h)
-        ops.call('dmh_sum_over_batch', ops.ptr(dwb), ops.ptr(dw), B, no * cf)
+        ops.call('dmh_sum_over_batch', ops.ptr(dwb), ops.ptr(dw), B * nk, no * cf)
         g['final_conv.weight'] = dw.reshape(sd['final_conv.weight'].shape)
-        ones = torch.ones((hw, 1), device=h.device, dtype=torch.float32)
-        dbb = ops._empty((B, no), h)
-        ops.bgemm(dout, (no * hw, 0, hw, 1), ones, (0, 0, 1, 1), dbb, (no, 0, 1, 1), no, 1, hw, B, 1)
+        ones = torch.ones((ks, 1), device=h.device, dtype=torch.float32)
+        dbb = ops._empty((B, nk, no), h)
+        ops.bgemm(dout, (no * hw, ks, hw, 1), ones, (0, 0, 1, 1), dbb, (nk * no, no, 1, 1), no, 1, ks, B, nk)
         db = ops._empty((no,), h)
-        ops.call('dmh_sum_over_batch', ops.ptr(dbb), ops.ptr(db), B, no)
+        ops.call('dmh_sum_over_batch', ops.ptr(dbb), ops.ptr(db), B * nk, no)
         g['final_conv.bias'] = db
         # ---- trunk, in reverse
         dss_all = torch.zeros((B, self.ss_total), device=h.device, dtype=torch.float32)
