@@ -1,4 +1,4 @@
-// Training, first pieces (in progress): weight and bias gradient of the stride-1 convolutions.
+// Training: weight and bias gradient of the stride-1 convolutions.
 //
 //   dW[o][c][ky][kx] = sum_{b,y,x} dY[b][y][x][o] * X[b][y+ky-p][x+kx-p][c]          db[o] = sum_{b,y,x} dY[b][y][x][o]
 //

@@ -140,13 +140,37 @@ __global__ __launch_bounds__(256) void gn_silu_bwd_apply_kernel(const float* __r
   }
 }
 
-// out[j][c] = sum_b in[b][j][c]  (per-sample parameter-gradient parts -> dgamma, dbeta), fixed order
-__global__ void sum_over_batch_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int64_t per) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= per) return;
+// out[i] = sum_b in[b][i]  (per-sample / per-block parameter-gradient parts -> the parameter gradient).  A workgroup owns
+// 16 consecutive outputs and spreads b over 16 thread groups: group g adds rows g, g+16, ... in order, then the 16 sums
+// are combined by a fixed tree — deterministic, and a long batch axis (1024 block partials) still fills the machine.
+__global__ __launch_bounds__(256) void sum_over_batch_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                             int64_t per) {
+  __shared__ float red[16][17];
+  const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t i = (int64_t)blockIdx.x * 16 + j;
   float s = 0.f;
-  for (int b = 0; b < B; ++b) s += in[(size_t)b * per + i];
-  out[i] = s;
+  if (i < per) {
+    const float* src = in + i;
+    int b = g;
+    for (; b + 48 < B; b += 64) {  // four loads in flight
+      const float v0 = src[(size_t)b * per], v1 = src[(size_t)(b + 16) * per];
+      const float v2 = src[(size_t)(b + 32) * per], v3 = src[(size_t)(b + 48) * per];
+      s = (((s + v0) + v1) + v2) + v3;
+    }
+    for (; b < B; b += 16) s += src[(size_t)b * per];
+  }
+  red[g][j] = s;
+  __syncthreads();
+  if (g == 0 && i < per) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = red[k][j];
+#pragma unroll
+    for (int w = 8; w; w >>= 1)
+#pragma unroll
+      for (int k = 0; k < w; ++k) t[k] = t[2 * k] + t[2 * k + 1];
+    out[i] = t[0];
+  }
 }
 
 // weight standardisation backward, one workgroup per output channel: wh = (w - m)*r, r = rsqrt(var + eps):
@@ -214,7 +238,7 @@ extern "C" int dmh_gn_silu_backward(const float* dout, const float* y, const flo
 
 extern "C" int dmh_sum_over_batch(const float* in, float* out, int B, int64_t per, void* stream) {
   DMH_REQUIRE(in && out && B > 0 && per > 0, "dmh_sum_over_batch: bad arguments");
-  hipLaunchKernelGGL(sum_over_batch_kernel, dim3((unsigned)cdiv64(per, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+  hipLaunchKernelGGL(sum_over_batch_kernel, dim3((unsigned)cdiv64(per, 16)), dim3(256), 0, (hipStream_t)stream, in, out,
                      B, per);
   DMH_CHECK_LAUNCH("dmh_sum_over_batch");
   return DMH_OK;

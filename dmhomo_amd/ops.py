@@ -569,7 +569,13 @@ def linear_backward(x, w, dy, want_bias=True):
     x, dy, w = x.contiguous(), dy.contiguous(), w.contiguous()
     dx = _empty((Bn, cin), x)
     dw = _empty((cout, cin), x)
-    bgemm(dy, (0, 0, cout, 1), w, (0, 0, cin, 1), dx, (0, 0, cin, 1), Bn, cin, cout, 1, 1)
+    if cout >= 1024 and cout % 128 == 0:       # long K (the stacked per-block MLPs): split it, add the parts in order
+        nk = cout // 128
+        part = _empty((nk, Bn, cin), x)
+        bgemm(dy, (0, 128, cout, 1), w, (0, 128 * cin, cin, 1), part, (0, Bn * cin, cin, 1), Bn, cin, 128, 1, nk)
+        call('dmh_sum_over_batch', ptr(part), ptr(dx), nk, Bn * cin)
+    else:
+        bgemm(dy, (0, 0, cout, 1), w, (0, 0, cin, 1), dx, (0, 0, cin, 1), Bn, cin, cout, 1, 1)
     bgemm(dy, (0, 0, 1, cout), x, (0, 0, cin, 1), dw, (0, 0, cin, 1), cout, cin, Bn, 1, 1)
     db = None
     if want_bias:

@@ -129,7 +129,7 @@ def sinusoidal_pos_emb(t, dim):
     """SinusoidalPosEmb.forward, CFG:165-172; ``t`` int64 (B,)."""
     half = dim // 2
     f = math.log(10000) / (half - 1)
-    f = torch.exp(torch.arange(half) * -f)
+    f = torch.exp(torch.arange(half, device=t.device) * -f)
     e = t[:, None] * f[None, :]
     return torch.cat((e.sin(), e.cos()), dim=-1)
 
