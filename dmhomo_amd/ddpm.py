@@ -397,7 +397,12 @@ class Trainer(object):
         self.gradient_accumulate_every = gradient_accumulate_every
         self.train_num_steps = train_num_steps
         self.image_size = diffusion_model.image_size
-        if isinstance(folder, (str, os.PathLike)):
+        if isinstance(folder, (str, os.PathLike)) and os.path.isfile(os.path.join(str(folder), 'BasesHomo_small.npy')):
+            from .dataset import UnHomoTrainData, ConditionLoader                       # DDP:1735-1752
+            self.ds = UnHomoTrainData(folder, self.image_size, augment_horizontal_flip=augment_horizontal_flip,
+                                      convert_image_to=convert_image_to, workers=max(1, num_worker))
+            self.dl = ConditionLoader(self.ds, train_batch_size, shuffle=shuffle)
+        elif isinstance(folder, (str, os.PathLike)):
             self.dl = SyntheticConditions(self.image_size, train_batch_size)
         else:
             self.dl = iter(folder)

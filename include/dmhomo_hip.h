@@ -304,6 +304,19 @@ int dmh_adam(float* p, const float* g, float* m, float* v, const float* gscale, 
              float eps, int step, void* stream);
 int dmh_ema(float* ema, const float* p, int64_t n, float decay, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------
+ * condition dataset path: UnHomoTrainData.__getitem__ DDP:1097-1163, a batch per launch
+ * ------------------------------------------------------------------------------------- */
+/* cv2.resize(img.astype(float32) / div, (Wd, Hd)) with INTER_LINEAR (DDP:1118-1123): src [B][Hs][Ws][C] uint8 interleaved
+ * (as decoded), dst plane c of image b at dst + b*dst_bstride + c*Hd*Wd (the batch tensor's own planes) */
+int dmh_resize_bilinear_u8(const unsigned char* src, float* dst, int B, int Hs, int Ws, int C, int Hd, int Wd,
+                           int64_t dst_bstride, float div, void* stream);
+/* cv2.dilate(cv2.erode(cv2.resize(mask, (Wd, Hd), INTER_NEAREST), ones(3,3)), ones(3,3)) (DDP:1129-1133):
+ * src [B][Hs][Ws] fp32, dst plane of image b at dst + b*dst_bstride */
+int dmh_mask_open_nearest(const float* src, float* dst, int B, int Hs, int Ws, int Hd, int Wd, int64_t dst_bstride,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
