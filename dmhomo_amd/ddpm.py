@@ -397,13 +397,16 @@ class Trainer(object):
         self.gradient_accumulate_every = gradient_accumulate_every
         self.train_num_steps = train_num_steps
         self.image_size = diffusion_model.image_size
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)     # each rank reads its own slice
         if isinstance(folder, (str, os.PathLike)) and os.path.isfile(os.path.join(str(folder), 'BasesHomo_small.npy')):
             from .dataset import UnHomoTrainData, ConditionLoader                       # DDP:1735-1752
             self.ds = UnHomoTrainData(folder, self.image_size, augment_horizontal_flip=augment_horizontal_flip,
                                       convert_image_to=convert_image_to, workers=max(1, num_worker))
-            self.dl = ConditionLoader(self.ds, train_batch_size, shuffle=shuffle)
+            self.dl = ConditionLoader(self.ds, train_batch_size, shuffle=shuffle, rank=rank, world=world)
         elif isinstance(folder, (str, os.PathLike)):
-            self.dl = SyntheticConditions(self.image_size, train_batch_size)
+            self.dl = SyntheticConditions(self.image_size, train_batch_size, seed=1000 + 100003 * rank)
         else:
             self.dl = iter(folder)
         self.ema = EMA(diffusion_model, beta=ema_decay, update_every=ema_update_every)

@@ -539,19 +539,8 @@ class TrainStep:
             self.lr, self.betas, self.eps = grp['lr'], tuple(grp['betas']), grp['eps']
 
     def _allreduce_mean(self, grads):
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-            return grads
-        names = list(grads)
-        flat = torch.cat([grads[k].reshape(-1) for k in names])           # one bucket: ~36M floats for the DGM UNet
-        dist.all_reduce(flat)
-        flat = ops.affine(flat, 1.0 / dist.get_world_size(), 0.)
-        out, o = {}, 0
-        for k in names:
-            n = grads[k].numel()
-            out[k] = flat[o:o + n].view(grads[k].shape)
-            o += n
-        return out
+        from .distributed import average_gradients
+        return average_gradients(grads, lambda flat, sc: ops.affine(flat, sc, 0.))
 
     def apply(self, grads):
         """clip by global norm, Adam, bump the weight epoch (the sampling engine and UnetTrain re-pack on it)."""

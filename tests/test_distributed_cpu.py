@@ -36,6 +36,10 @@ def _worker(rank, world, port, q):
     rng = D.SampleIndexedRng(7, range(slo, shi), device)
     n1 = rng.randn((shi - slo, 2, 3), device)
     u1 = rng.uniform(shi - slo, device)
+    # training: gradient averaging (the scale step is a HIP kernel on the GPU path; a torch multiply stands in here)
+    grads = {'b.weight': torch.full((2, 3), float(rank + 1)), 'a.bias': torch.arange(4.) * (rank + 1)}
+    avg = D.average_gradients(grads, lambda flat, sc: flat * sc)
+    assert torch.equal(avg['b.weight'], torch.full((2, 3), 1.5)) and torch.equal(avg['a.bias'], torch.arange(4.) * 1.5)
     q.put((rank, digest, (lo, hi), None if gi is None else gi[:, 0, 0, 0].tolist(),
            None if gh is None else gh[:, 0, 0].tolist(), n1.tolist(), u1.tolist()))   # plain lists: no shm fds
     torch.distributed.barrier()
