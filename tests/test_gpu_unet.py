@@ -138,6 +138,7 @@ def test_fullsize_rows_independent_and_cfg_modes_agree():
     outs = {}
     for mode in ('batched', 'streams'):
         m.cfg_mode = mode
+        torch.manual_seed(5)          # the conditional pass draws its class-dropout mask (CFG:404 -> CFG:422), like the reference
         outs[mode] = m.forward_with_cond_scale(g(x), g(t), g(c), g(rf), g(mk), cond_scale=3.).clone()
     assert torch.isfinite(outs['batched']).all()
     assert torch.equal(outs['batched'], outs['streams'])
