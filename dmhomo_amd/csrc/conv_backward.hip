@@ -50,6 +50,7 @@ struct WgArgs {
   int B, H, W, C0, C1, Cout;  // H, W: size of dy (= conv output)
   int Hin, Win, ups;          // stored input size; ups: the conv saw the nearest-x2 upsampling of it (Upsample, CFG:106-107)
   int tilesX, tilesY, nitems, nsplit, ctiles;
+  int ablate;  // diagnostics (DMH_WG_ABL): 1 skip the MFMA phase, 2 skip the global loads, 4 skip the split + LDS writes, 8 skip the partial store
 };
 
 template <int KH, int NCB, int PAD>
@@ -154,6 +155,356 @@ __global__ __launch_bounds__(256, NCB == 4 ? 2 : 1) void conv_wgrad_kernel(WgArg
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same GEMM on the fp16 matrix cores (v_mfma_f32_16x16x32_f16), with the operand split of conv_f16x3.hip: each fp32
+// operand is two block-scaled fp16 pieces and a product block takes three MFMAs, accumulated in fp32 — the error sits at
+// the fp32-accumulation level at about a third of the exact-fp32 kernel's matrix time.
+//
+// The fp16 MFMA wants its K values (here: PIXELS) 8-contiguous per lane, but NHWC keeps channels contiguous.  The
+// transposition happens while staging: a thread loads 4 consecutive pixels x 4 channels (float4 per pixel, 256 B per
+// pixel across 16 lanes), scales, splits, and writes per channel one 8-byte run of 4 pixels into channel-major planes
+//     dY:  [o][4 rows x 16 px]  fp16, pitch 144 B            X:  [c][6 rows x 24 px]  fp16, pitch 304 B
+// (both pitches an odd number of 16-byte units: the 16 lanes of a ds_read_b128 phase hit 16 distinct bank groups).
+// A K step of 32 = 4 tile rows (the lane's K group) x 8 pixels of a half row; the tap's x shift (0..2 pixels = 0..4
+// bytes) cannot be an aligned 16-byte read, so a lane reads its 8 pixels + the next 2 once per (ky, channel block) and
+// forms the three kx operands in registers (v_alignbit for the odd shift, plain re-indexing for the even one).
+// Scales: per workgroup, running maxima of |dY| and |X| over its items (as in conv_f16x3.hip): when a later item raises a
+// maximum the accumulators are multiplied by the (power-of-two) ratio, so the scale only shrinks and nothing overflows.
+//     d1 = fp16(d*sd)  d2 = fp16(d*sd - d1)  d1s = d1 * 2^-11 (registers)      x1 = fp16(x*sx)  x2 = fp16((x*sx - x1) * 2^11)
+//     d*x*sd*sx = d1*x1 + d2*x1 + d1s*x2 + O(2^-22)
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+namespace {
+template <int KH>
+struct WhCfg {
+  static constexpr int NT = KH * KH;
+  static constexpr int XH = TH + KH - 1, XW = TW + KH - 1;
+  static constexpr int XG = (XW + 3) / 4;                       // 4-pixel staging groups per halo row
+  static constexpr int XROWB = ((XW + 7) / 8 * 8) * 2;          // bytes per halo row (pixels padded to 8)
+  static constexpr int XPITCH = ((XH * XROWB / 16) | 1) * 16;   // bytes per input channel: an odd number of 16-byte units
+  static constexpr int APITCH = TP * 2 + 16;                    // bytes per output channel: 64 px
+  static constexpr int A_BYTES = 64 * APITCH, X_BYTES = 16 * XPITCH;
+  static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * X_BYTES + 64;   // planes + the maxima slots
+  static constexpr int XSLOTS = XH * XG * 4;                    // X staging slots (4 px x 4 c each) per item, <= 256
+};
+__device__ __forceinline__ float amax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ int max_exponent(unsigned bits) {  // v in [2^e, 2^(e+1)); all-zero / tiny tiles clamp at -100
+  const int e = (int)((bits >> 23) & 0xff) - 127;
+  return e < -100 ? -100 : e;
+}
+}  // namespace
+
+// Workgroup = 4 waves: 64 output channels (wave w: 16w..16w+15) x ONE 16-channel input block x all taps, over a
+// contiguous range of (sample, 4x16-pixel tile) items.  grid = (pixel splits, 64x64 pairs * 4 channel blocks): a
+// quarter of the accumulators of the fp32 kernel (9 x 4 registers for 3x3), so four workgroups fit a CU and hide each
+// other's staging, and a pixel split costs a quarter of the partial block.  dY is staged by all four channel-block
+// workgroups of a pair (they share a split index modulo 8, hence an XCD and its L2).
+template <int KH, int PAD>
+__global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
+  using Cfg = WhCfg<KH>;
+  constexpr int NT = Cfg::NT, XW = Cfg::XW, XG = Cfg::XG, XROWB = Cfg::XROWB, XPITCH = Cfg::XPITCH, APITCH = Cfg::APITCH;
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  char* a1 = ldsb;
+  char* a2 = a1 + Cfg::A_BYTES;
+  char* x1 = a2 + Cfg::A_BYTES;
+  char* x2 = x1 + Cfg::X_BYTES;
+  unsigned* mx = reinterpret_cast<unsigned*>(x2 + Cfg::X_BYTES);  // [parity][0 dY, 1 X] max |value| bits
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  const int split = blockIdx.x;
+  const int pair = blockIdx.y >> 2, cbq = blockIdx.y & 3, ot = pair / p.ctiles, ct = pair % p.ctiles;
+  const int o0 = ot * 64, c0 = ct * 64 + cbq * 16;
+  const int Cin = p.C0 + p.C1;
+  const int Hv = p.ups ? p.Hin * 2 : p.Hin, Wv = p.ups ? p.Win * 2 : p.Win;
+  if (c0 >= Cin) return;  // a channel block beyond the input channels (Cin not a multiple of 64): its slice stays unread
+
+  float4v acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread's 4 output channels, summed over its pixels
+  int ed = -127, ex = -127;                        // running exponents of the maxima
+  if (tid < 4) mx[tid] = 0u;
+  __syncthreads();
+
+  const int per = (p.nitems + p.nsplit - 1) / p.nsplit;
+  const int i0 = split * per, i1 = min(i0 + per, p.nitems);
+  const int q4 = tid & 15, pg = tid >> 4;  // dY staging: channel quad, pixel group
+  const int xq = tid & 3, xgi = tid >> 2;  // X staging: channel quad (of this block's 4), (row, pixel group)
+  const int xrow = xgi / XG, xg = xgi % XG;
+  const bool xslot = tid < Cfg::XSLOTS;
+
+  for (int item = i0; item < i1; ++item) {
+    const int par = (item - i0) & 1;
+    const int tx = item % p.tilesX, ty = (item / p.tilesX) % p.tilesY, b = item / (p.tilesX * p.tilesY);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    // ---- global -> registers: dY, 4 px x 4 o per thread
+    float4 dv[4];
+    {
+      const int y = oy0 + (pg >> 2), o = o0 + q4 * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = ox0 + (pg & 3) * 4 + j;
+        dv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(p.ablate & 2) && y < p.H && x < p.W && o < p.Cout)
+          dv[j] = ld4(p.dy + ((size_t)(b * p.H + y) * p.W + x) * p.Cout + o);
+      }
+    }
+    // ---- X halo, 4 px x 4 c per slot (the conv's input as it saw it: concat, GroupNorm+SiLU prologue, x2 upsampling)
+    float4 xv[4];
+    {
+      const int c = c0 + xq * 4;
+      const int y = oy0 - PAD + xrow;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int xl = xg * 4 + j, x = ox0 - PAD + xl;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(p.ablate & 2) && xslot && xl < XW && y >= 0 && y < Hv && x >= 0 && x < Wv && c < Cin) {
+          const int sy = p.ups ? (y >> 1) : y, sx = p.ups ? (x >> 1) : x;
+          const size_t pixoff = (size_t)(b * p.Hin + sy) * p.Win + sx;
+          if (c < p.C0) {
+            v = ld4(p.src0 + pixoff * p.C0 + c);
+            if (p.in_coef) {
+              const float4 a = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + c);
+              const float4 bb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + c);
+              v.x = silu_f(fmaf(a.x, v.x, bb.x));
+              v.y = silu_f(fmaf(a.y, v.y, bb.y));
+              v.z = silu_f(fmaf(a.z, v.z, bb.z));
+              v.w = silu_f(fmaf(a.w, v.w, bb.w));
+            }
+          } else {
+            v = ld4(p.src1 + pixoff * p.C1 + (c - p.C0));
+          }
+        }
+        xv[j] = v;
+      }
+    }
+    // ---- tile maxima -> LDS (non-negative floats order like their bit patterns)
+    float md = 0.f, mxx = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      md = fmaxf(md, amax4(dv[j]));
+      mxx = fmaxf(mxx, amax4(xv[j]));
+      bsum.x += dv[j].x;
+      bsum.y += dv[j].y;
+      bsum.z += dv[j].z;
+      bsum.w += dv[j].w;
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+      md = fmaxf(md, __shfl_xor(md, off));
+      mxx = fmaxf(mxx, __shfl_xor(mxx, off));
+    }
+    if (lane == 0) {
+      atomicMax(&mx[par * 2 + 0], __float_as_uint(md));
+      atomicMax(&mx[par * 2 + 1], __float_as_uint(mxx));
+    }
+    __syncthreads();  // (A) maxima complete; every wave is past the previous item's fragment reads
+    const int nd = max(ed, max_exponent(mx[par * 2 + 0])), nx = max(ex, max_exponent(mx[par * 2 + 1]));
+    if (nd + nx != ed + ex) {  // workgroup-uniform
+      const float f = ldexpf(1.f, max((ed + ex) - (nd + nx), -120));
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] *= f;
+      ed = nd;
+      ex = nx;
+    }
+    if (tid < 2) mx[(par ^ 1) * 2 + tid] = 0u;  // the other parity's slots, for the next item
+    const float sd = ldexpf(1.f, 14 - ed), sx_ = ldexpf(1.f, 14 - ex);
+    // ---- split + transposed LDS writes: per channel one run of 4 pixels
+    if (!(p.ablate & 4)) {
+      const int pixb = ((pg >> 2) * TW + (pg & 3) * 4) * 2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        half4 h1, h2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = (i == 0 ? dv[j].x : i == 1 ? dv[j].y : i == 2 ? dv[j].z : dv[j].w) * sd;
+          const _Float16 t1 = (_Float16)v;
+          h1[j] = t1;
+          h2[j] = (_Float16)(v - (float)t1);
+        }
+        *reinterpret_cast<half4*>(a1 + (q4 * 4 + i) * APITCH + pixb) = h1;
+        *reinterpret_cast<half4*>(a2 + (q4 * 4 + i) * APITCH + pixb) = h2;
+      }
+      if (xslot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          half4 h1, h2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = (i == 0 ? xv[j].x : i == 1 ? xv[j].y : i == 2 ? xv[j].z : xv[j].w) * sx_;
+            const _Float16 t1 = (_Float16)v;
+            h1[j] = t1;
+            h2[j] = (_Float16)((v - (float)t1) * 2048.f);
+          }
+          *reinterpret_cast<half4*>(x1 + (xq * 4 + i) * XPITCH + xrow * XROWB + xg * 8) = h1;
+          *reinterpret_cast<half4*>(x2 + (xq * 4 + i) * XPITCH + xrow * XROWB + xg * 8) = h2;
+        }
+      }
+    }
+    __syncthreads();  // (B) tiles staged
+    // ---- 2 K steps of 32 pixels (4 tile rows x 8 pixels of a half row)
+    if (!(p.ablate & 1))
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const char* ap = a1 + (wave * 16 + l15) * APITCH + (kg * TW + half * 8) * 2;
+        const half8 d1 = *reinterpret_cast<const half8*>(ap);
+        const half8 d2 = *reinterpret_cast<const half8*>(ap + Cfg::A_BYTES);
+        const half8 d1s = d1 * (_Float16)(1.0f / 2048.0f);
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+          const char* xp = x1 + l15 * XPITCH + (kg + ky) * XROWB + half * 16;
+          const uint4v u1 = *reinterpret_cast<const uint4v*>(xp);
+          const uint4v u2 = *reinterpret_cast<const uint4v*>(xp + Cfg::X_BYTES);
+          unsigned e1 = 0u, e2 = 0u;
+          if (KH > 1) {
+            e1 = *reinterpret_cast<const unsigned*>(xp + 16);
+            e2 = *reinterpret_cast<const unsigned*>(xp + Cfg::X_BYTES + 16);
+          }
+          half8 b1[KH], b2[KH];
+#pragma unroll
+          for (int kx = 0; kx < KH; ++kx) {
+            uint4v s1 = u1, s2 = u2;
+            if (kx == 1) {
+              s1 = uint4v{__builtin_amdgcn_alignbit(u1.y, u1.x, 16), __builtin_amdgcn_alignbit(u1.z, u1.y, 16),
+                          __builtin_amdgcn_alignbit(u1.w, u1.z, 16), __builtin_amdgcn_alignbit(e1, u1.w, 16)};
+              s2 = uint4v{__builtin_amdgcn_alignbit(u2.y, u2.x, 16), __builtin_amdgcn_alignbit(u2.z, u2.y, 16),
+                          __builtin_amdgcn_alignbit(u2.w, u2.z, 16), __builtin_amdgcn_alignbit(e2, u2.w, 16)};
+            } else if (kx == 2) {
+              s1 = uint4v{u1.y, u1.z, u1.w, e1};
+              s2 = uint4v{u2.y, u2.z, u2.w, e2};
+            }
+            b1[kx] = __builtin_bit_cast(half8, s1);
+            b2[kx] = __builtin_bit_cast(half8, s2);
+          }
+          // the three terms, each across the kx accumulators: consecutive MFMAs never share an accumulator
+#pragma unroll
+          for (int kx = 0; kx < KH; ++kx)
+            acc[ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1s, b2[kx], acc[ky * KH + kx], 0, 0, 0);
+#pragma unroll
+          for (int kx = 0; kx < KH; ++kx)
+            acc[ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2, b1[kx], acc[ky * KH + kx], 0, 0, 0);
+#pragma unroll
+          for (int kx = 0; kx < KH; ++kx)
+            acc[ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, b1[kx], acc[ky * KH + kx], 0, 0, 0);
+        }
+      }
+  }
+
+  // ---- partial block, un-scaled.  Layout [tap][channel block][wave][kg][l15][r]: one 16-byte store per lane, 1 KB
+  // contiguous per wave (conv_wgrad_reduce_v2_kernel undoes the permutation while it writes the 147 KB of dW)
+  const float osc = ldexpf(1.f, max(ed + ex - 28, -126));
+  float* pw = p.part_w + ((size_t)(split * (gridDim.y >> 2) + pair) * 64 * 64) * NT;
+  if (!(p.ablate & 8))
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float4v v = acc[t] * osc;
+      *reinterpret_cast<float4v*>(pw + ((size_t)((t * 4 + cbq) * 4 + wave) * 4 + kg) * 64 + l15 * 4) = v;
+    }
+  if (ct == 0 && cbq == 0) {  // bias partial: the 16 pixel groups of a channel quad -> one sum per output channel, fixed order
+    __syncthreads();
+    float* br = reinterpret_cast<float*>(a1);  // [16 pg][64 o]
+    st4(br + pg * 64 + q4 * 4, bsum);
+    __syncthreads();
+    if (tid < 64) {
+      float sb = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sb += br[g * 64 + tid];
+      p.part_b[((size_t)split * ((gridDim.y >> 2) / p.ctiles) + ot) * 64 + tid] = sb;
+    }
+  }
+}
+
+// dW from the partial blocks of conv_wgrad_f16x3_kernel.  A thread owns one 16-byte unit (4 output channels) of the
+// block layout; a workgroup 16 consecutive units x 16 split groups: group g adds splits g, g+16, ... in order, then the
+// 16 sums are combined by a fixed tree; the result is scattered to OIHW.  db as in the fp32 path.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_v2_kernel(const float* __restrict__ part_w,
+                                                                   const float* __restrict__ part_b, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int Cout, int Cin, int NT,
+                                                                   int nsplit, int otiles, int ctiles) {
+  __shared__ float4 red[16][17];
+  const int j = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int64_t unit = (int64_t)blockIdx.x * 16 + j;  // float4 index inside [pair][t][cb][wave][kg][l15]
+  const int64_t units = (int64_t)otiles * ctiles * NT * 1024;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const size_t stride = (size_t)otiles * ctiles * 64 * 64 * NT;
+  if (unit < units) {
+    const float* src = part_w + unit * 4;
+    int sp = g;
+    for (; sp + 48 < nsplit; sp += 64) {
+      const float4 v0 = ld4(src + (size_t)sp * stride), v1 = ld4(src + (size_t)(sp + 16) * stride);
+      const float4 v2 = ld4(src + (size_t)(sp + 32) * stride), v3 = ld4(src + (size_t)(sp + 48) * stride);
+      s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x;
+      s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+      s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z;
+      s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; sp < nsplit; sp += 16) {
+      const float4 v = ld4(src + (size_t)sp * stride);
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+  }
+  red[g][j] = s;
+  __syncthreads();
+  if (g == 0 && unit < units) {
+    float4 t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = red[k][j];
+#pragma unroll
+    for (int w = 8; w; w >>= 1)
+#pragma unroll
+      for (int k = 0; k < w; ++k) {
+        t[k].x = t[2 * k].x + t[2 * k + 1].x;
+        t[k].y = t[2 * k].y + t[2 * k + 1].y;
+        t[k].z = t[2 * k].z + t[2 * k + 1].z;
+        t[k].w = t[2 * k].w + t[2 * k + 1].w;
+      }
+    int64_t u = unit;
+    const int l15 = u % 16;
+    u /= 16;
+    const int kg = u % 4;
+    u /= 4;
+    const int wave = u % 4;
+    u /= 4;
+    const int cb = u % 4;
+    u /= 4;
+    const int tap = u % NT;
+    const int pair = u / NT;
+    const int c = (pair % ctiles) * 64 + cb * 16 + l15;
+    const int ob = (pair / ctiles) * 64 + wave * 16 + kg * 4;
+    const float r[4] = {t[0].x, t[0].y, t[0].z, t[0].w};
+    if (c < Cin)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ob + i < Cout) dw[((size_t)(ob + i) * Cin + c) * NT + tap] = r[i];
+  }
+  // db: workgroup i owns output channels 16i..16i+15, the same 16 split groups and tree
+  if (db && (int)blockIdx.x * 16 < Cout) {
+    const int o = blockIdx.x * 16 + j;
+    float sb = 0.f;
+    if (o < Cout)
+      for (int sp = g; sp < nsplit; sp += 16) sb += part_b[((size_t)sp * otiles + o / 64) * 64 + o % 64];
+    __syncthreads();
+    red[g][j].x = sb;
+    __syncthreads();
+    if (g == 0 && o < Cout) {
+      float t[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t[k] = red[k][j].x;
+#pragma unroll
+      for (int w = 8; w; w >>= 1)
+#pragma unroll
+        for (int k = 0; k < w; ++k) t[k] = t[2 * k] + t[2 * k + 1];
+      db[o] = t[0];
+    }
+  }
+}
+
 // dW[o][c][tap] (OIHW, Cin = C0 + C1) = sum over the pixel splits; same for db.  A workgroup owns 64 consecutive outputs
 // (one 256-byte row of every partial block: coalesced) and spreads the splits over its 4 waves: wave g adds splits
 // g, g+4, ... in order, then the four sums are combined as (s0 + s1) + (s2 + s3) — a fixed tree, the same bits every run.
@@ -185,12 +536,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   red[g][j] = s;
   __syncthreads();
   if (g == 0 && idx < total) dw[idx] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
-  if (db && blockIdx.x == 0) {
-    for (int o = threadIdx.x; o < Cout; o += 256) {
-      float sb = 0.f;
-      for (int sp = 0; sp < nsplit; ++sp) sb += part_b[((size_t)sp * otiles + o / 64) * 64 + o % 64];
-      db[o] = sb;
-    }
+  // db: workgroup i owns output channels 64i..64i+63, the same 4 split groups and tree
+  if (db && (int)blockIdx.x * 64 < Cout) {
+    const int o = blockIdx.x * 64 + j;
+    float sb = 0.f;
+    if (o < Cout)
+      for (int sp = g; sp < nsplit; sp += 4) sb += part_b[((size_t)sp * otiles + o / 64) * 64 + o % 64];
+    __syncthreads();
+    red[g][j] = sb;
+    __syncthreads();
+    if (g == 0 && o < Cout) db[o] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
   }
 }
 
@@ -198,6 +553,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 // partial block written and read back
 static int wgrad_splits(int nitems, int npairs) {
   int s = 512 / (npairs > 0 ? npairs : 1);
+  if (s < 1) s = 1;
+  if (s > nitems) s = nitems;
+  return s;
+}
+// fp16-piece kernels: about 1024 workgroups (4 per CU) over (splits, pairs * 4 channel blocks); splits a multiple of 8 where
+// possible so that the four channel-block workgroups of a pair share an XCD (linear workgroup id modulo 8)
+static int wgrad_splits_f16(int nitems, int npairs) {
+  int s = 1024 / (4 * (npairs > 0 ? npairs : 1));
+  if (s >= 8) s = s / 8 * 8;
   if (s < 1) s = 1;
   if (s > nitems) s = nitems;
   return s;
@@ -210,7 +574,8 @@ static int wgrad_cw(int KH) { return KH == 7 ? 16 : 64; }  // input channels per
 extern "C" int64_t dmh_conv_wgrad_workspace_floats(int B, int H, int W, int C0, int C1, int Cout, int KH) {
   const int npairs = cdiv(Cout, 64) * cdiv(C0 + C1, wgrad_cw(KH));
   const int nitems = B * cdiv(H, TH) * cdiv(W, TW);
-  const int ns = wgrad_splits(nitems, npairs);
+  int ns = wgrad_splits(nitems, npairs);
+  if ((KH == 2 || KH == 3) && wgrad_splits_f16(nitems, npairs) > ns) ns = wgrad_splits_f16(nitems, npairs);
   return (int64_t)ns * npairs * 64 * 64 * KH * KH + (int64_t)ns * cdiv(Cout, 64) * 64;
 }
 
@@ -218,6 +583,20 @@ template <int KH, int NCB, int PAD>
 static void launch_wgrad(const WgArgs& a, dim3 grid, hipStream_t st) {
   using Cfg = WgCfg<KH, NCB, PAD>;
   auto kern = conv_wgrad_kernel<KH, NCB, PAD>;
+  if (Cfg::LDS_BYTES > 64 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+      attr = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, a);
+}
+
+template <int KH, int PAD>
+static void launch_wgrad_f16(const WgArgs& a, dim3 grid, hipStream_t st) {
+  using Cfg = WhCfg<KH>;
+  auto kern = conv_wgrad_f16x3_kernel<KH, PAD>;
   if (Cfg::LDS_BYTES > 64 * 1024) {
     static bool attr = false;
     if (!attr) {
@@ -259,20 +638,43 @@ extern "C" int dmh_conv_wgrad(const float* dy, const float* src0, const float* s
   const int cw = wgrad_cw(KH);
   a.ctiles = cdiv(a.C0 + a.C1, cw);
   const int otiles = cdiv(Cout, 64), npairs = otiles * a.ctiles;
-  a.nsplit = wgrad_splits(a.nitems, npairs);
+  static const int abl = [] {
+    const char* e = getenv("DMH_WG_ABL");
+    return e ? atoi(e) : 0;
+  }();
+  a.ablate = abl;
+  static const int variant = [] {  // DMH_WGRAD_VARIANT=0: the exact-fp32 MFMA kernels everywhere
+    const char* e = getenv("DMH_WGRAD_VARIANT");
+    return e ? atoi(e) : 1;
+  }();
+  const bool f16 = variant == 1 && (KH == 2 || KH == 3);  // 1x1: too little matrix work per staged dY tile, the fp32 kernel wins
+  a.nsplit = f16 ? wgrad_splits_f16(a.nitems, npairs) : wgrad_splits(a.nitems, npairs);
   a.part_w = work;
   a.part_b = work + (int64_t)a.nsplit * npairs * 64 * 64 * KH * KH;
-  dim3 grid(a.nsplit, npairs);
-  switch (KH) {
-    case 1: launch_wgrad<1, 4, 0>(a, grid, st); break;
-    case 2: launch_wgrad<2, 4, 0>(a, grid, st); break;
-    case 3: launch_wgrad<3, 4, 1>(a, grid, st); break;
-    default: launch_wgrad<7, 1, 3>(a, grid, st); break;
+  if (f16) {
+    dim3 grid(a.nsplit, npairs * 4);
+    switch (KH) {
+      case 1: launch_wgrad_f16<1, 0>(a, grid, st); break;
+      case 2: launch_wgrad_f16<2, 0>(a, grid, st); break;
+      default: launch_wgrad_f16<3, 1>(a, grid, st); break;
+    }
+    DMH_CHECK_LAUNCH("dmh_conv_wgrad");
+    const int64_t units = (int64_t)npairs * KH * KH * 1024;
+    hipLaunchKernelGGL(conv_wgrad_reduce_v2_kernel, dim3((unsigned)cdiv64(units, 16)), dim3(256), 0, st, a.part_w, a.part_b, dw,
+                       db, Cout, a.C0 + a.C1, KH * KH, a.nsplit, otiles, a.ctiles);
+  } else {
+    dim3 grid(a.nsplit, npairs);
+    switch (KH) {
+      case 1: launch_wgrad<1, 4, 0>(a, grid, st); break;
+      case 2: launch_wgrad<2, 4, 0>(a, grid, st); break;
+      case 3: launch_wgrad<3, 4, 1>(a, grid, st); break;
+      default: launch_wgrad<7, 1, 3>(a, grid, st); break;
+    }
+    DMH_CHECK_LAUNCH("dmh_conv_wgrad");
+    const int64_t total = (int64_t)Cout * (a.C0 + a.C1) * KH * KH;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 64)), dim3(256), 0, st, a.part_w, a.part_b, dw,
+                       db, Cout, a.C0 + a.C1, KH * KH, a.nsplit, otiles, a.ctiles, cw);
   }
-  DMH_CHECK_LAUNCH("dmh_conv_wgrad");
-  const int64_t total = (int64_t)Cout * (a.C0 + a.C1) * KH * KH;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)cdiv64(total, 64)), dim3(256), 0, st,
-                     a.part_w, a.part_b, dw, db, Cout, a.C0 + a.C1, KH * KH, a.nsplit, otiles, a.ctiles, cw);
   DMH_CHECK_LAUNCH("dmh_conv_wgrad(reduce)");
   return DMH_OK;
 }
