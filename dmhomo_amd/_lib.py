@@ -82,6 +82,10 @@ SIGNATURES = {
     'dmh_adam': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_float, c_float, c_float, c_float, c_int,
                          C.c_void_p]),
     'dmh_ema': (c_int, [c_f32p, c_f32p, c_i64, c_float, C.c_void_p]),
+    'dmh_multi_blocks': (c_i64, [C.c_void_p, c_int]),
+    'dmh_sumsq_multi': (c_int, [C.c_void_p, C.c_void_p, c_int, c_f32p, C.c_void_p]),
+    'dmh_adam_multi': (c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int, c_f32p, c_float, c_float,
+                               c_float, c_float, c_int, C.c_void_p]),
     'dmh_resize_bilinear_u8': (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_float,
                                        C.c_void_p]),
     'dmh_mask_open_nearest': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_i64, C.c_void_p]),

@@ -208,6 +208,110 @@ extern "C" int dmh_adam(float* p, const float* g, float* m, float* v, const floa
   DMH_CHECK_LAUNCH("dmh_adam");
   return DMH_OK;
 }
+// ---- multi-tensor forms: the ~280 parameter tensors of the UNet in a handful of launches.  A launch carries up to
+// MT_MAX tensors in its kernel arguments (pointers, lengths, first block of each); a block finds its tensor by binary
+// search and handles MT_CHUNK consecutive elements of it.
+#define MT_MAX 48
+#define MT_CHUNK 4096
+struct MtTable {
+  float* p[MT_MAX];
+  const float* g[MT_MAX];
+  float* m[MT_MAX];
+  float* v[MT_MAX];
+  long long n[MT_MAX];
+  int blk0[MT_MAX + 1];
+  int count;
+};
+__device__ __forceinline__ int mt_find(const MtTable& t, int blk) {
+  int lo = 0, hi = t.count;  // blk0[lo] <= blk < blk0[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.blk0[mid] <= blk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(MtTable t, double* __restrict__ part) {
+  __shared__ double red[4];
+  const int ti = mt_find(t, blockIdx.x);
+  const long long base = (long long)(blockIdx.x - t.blk0[ti]) * MT_CHUNK;
+  const float* g = t.g[ti];
+  const long long end = min(base + MT_CHUNK, t.n[ti]);
+  double s = 0.0;
+  for (long long i = base + threadIdx.x; i < end; i += 256) s += (double)g[i] * g[i];
+  for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void adam_multi_kernel(MtTable t, const float* __restrict__ gscale, float lr, float b1,
+                                                         float b2, float eps, float bc1, float bc2) {
+  const int ti = mt_find(t, blockIdx.x);
+  const long long base = (long long)(blockIdx.x - t.blk0[ti]) * MT_CHUNK;
+  const long long end = min(base + MT_CHUNK, t.n[ti]);
+  float* p = t.p[ti];
+  const float* g = t.g[ti];
+  float* m = t.m[ti];
+  float* v = t.v[ti];
+  const float gs = gscale ? gscale[1] : 1.f;
+  for (long long i = base + threadIdx.x; i < end; i += 256) {
+    const float gr = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+  }
+}
+// blocks dmh_sumsq_multi writes partials for (the size of ``part``)
+extern "C" int64_t dmh_multi_blocks(const int64_t* n, int count) {
+  int64_t b = 0;
+  for (int i = 0; i < count; ++i) b += cdiv64(n[i], MT_CHUNK);
+  return b;
+}
+static int mt_fill(MtTable& t, int i0, int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                   const int64_t* n) {
+  int blocks = 0, k = 0;
+  for (; k < MT_MAX && i0 + k < count; ++k) {
+    t.p[k] = p ? p[i0 + k] : nullptr;
+    t.g[k] = g[i0 + k];
+    t.m[k] = m ? m[i0 + k] : nullptr;
+    t.v[k] = v ? v[i0 + k] : nullptr;
+    t.n[k] = n[i0 + k];
+    t.blk0[k] = blocks;
+    blocks += (int)cdiv64(n[i0 + k], MT_CHUNK);
+  }
+  t.blk0[k] = blocks;
+  t.count = k;
+  return blocks;
+}
+// g, n: HOST arrays of ``count`` device pointers / lengths; part: f64 [dmh_multi_blocks(n, count)]
+extern "C" int dmh_sumsq_multi(const float* const* g, const int64_t* n, int count, double* part, void* stream) {
+  DMH_REQUIRE(g && n && part && count > 0, "dmh_sumsq_multi: bad arguments");
+  int64_t done = 0;
+  for (int i0 = 0; i0 < count; i0 += MT_MAX) {
+    MtTable t;
+    const int blocks = mt_fill(t, i0, count, nullptr, g, nullptr, nullptr, n);
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, part + done);
+    done += blocks;
+  }
+  DMH_CHECK_LAUNCH("dmh_sumsq_multi");
+  return DMH_OK;
+}
+extern "C" int dmh_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                              int count, const float* gscale, float lr, float b1, float b2, float eps, int step,
+                              void* stream) {
+  DMH_REQUIRE(p && g && m && v && n && count > 0 && step > 0, "dmh_adam_multi: bad arguments");
+  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  for (int i0 = 0; i0 < count; i0 += MT_MAX) {
+    MtTable t;
+    const int blocks = mt_fill(t, i0, count, p, g, m, v, n);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, t, gscale, lr, b1, b2, eps, bc1,
+                       bc2);
+  }
+  DMH_CHECK_LAUNCH("dmh_adam_multi");
+  return DMH_OK;
+}
 extern "C" int dmh_ema(float* ema, const float* p, int64_t n, float decay, void* stream) {
   DMH_REQUIRE(ema && p && n > 0, "dmh_ema: bad arguments");
   hipLaunchKernelGGL(ema_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, ema, p, n, decay);

@@ -435,7 +435,7 @@ class Trainer(object):
             if self._ts is not None:
                 self._ts.load_state_dict(self._opt_state)
         if self._ts is not None:
-            self._ts.ut.refresh()
+            self._ts.refresh()
         if 'version' in data:
             print(f"loading from version {data['version']}")
 

@@ -621,3 +621,25 @@ def adam_(p, g, m, v, gscale, lr, b1, b2, eps, step):
 def ema_(ema, p, decay):
     """ema <- ema * decay + p * (1 - decay), in place."""
     call('dmh_ema', ptr(ema), ptr(p), p.numel(), float(decay))
+
+
+def _ptr_table(tensors):
+    for t in tensors:
+        assert t.is_cuda and t.dtype == F32 and t.is_contiguous()
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def clip_adam_multi_(params, grads, ms, vs, max_norm, lr, b1, b2, eps, step):
+    """clip_grad_norm_ + Adam.step (DDP:1852-1857) over lists of tensors in a handful of launches (dmh_sumsq_multi,
+    dmh_gradnorm_finalize, dmh_adam_multi).  -> (2,) tensor [total norm, clip coefficient]"""
+    n = len(params)
+    sizes = (C.c_int64 * n)(*[p.numel() for p in params])
+    gt = _ptr_table(grads)
+    nb = int(lib().dmh_multi_blocks(sizes, n))
+    part = torch.empty((nb,), device=params[0].device, dtype=torch.float64)
+    call('dmh_sumsq_multi', gt, sizes, n, ptr(part, torch.float64))
+    clip = torch.empty((2,), device=params[0].device, dtype=F32)
+    call('dmh_gradnorm_finalize', ptr(part, torch.float64), nb, float(max_norm), ptr(clip))
+    call('dmh_adam_multi', _ptr_table(params), gt, _ptr_table(ms), _ptr_table(vs), sizes, n, ptr(clip), float(lr), float(b1),
+         float(b2), float(eps), int(step))
+    return clip

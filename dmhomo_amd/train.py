@@ -15,6 +15,8 @@ whole conditional UNet (CFG:412-466) with a manual tape; ``TrainStep`` adds p_lo
 gradient accumulation, the global-norm clip, Adam and the RCCL gradient all-reduce: one optimiser step of
 ``Trainer.train`` (DDP:1830-1862).  There is no autograd anywhere on this path.
 """
+import os
+
 import torch
 
 from . import ops
@@ -169,7 +171,8 @@ class UnetTrain:
         self.dim = sd['time_mlp.1.weight'].shape[1]
         half = self.dim // 2
         import math
-        self.freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(sd['init_conv.weight'].device)
+        if getattr(self, 'freq', None) is None:      # constant: built once (a host->device copy cannot sit in a HIP graph)
+            self.freq = torch.exp(torch.arange(half) * -(math.log(10000) / (half - 1))).to(sd['init_conv.weight'].device)
         dev = sd['init_conv.weight'].device
         w0 = sd['init_conv.weight']
         self.cin = w0.shape[1]
@@ -470,6 +473,9 @@ class TrainStep:
         self.v = {k: torch.zeros_like(p) for k, p in self.params.items()}
         self.opt_step = 0
         self.last_norm = None
+        # the weight re-pack after every optimiser step (~1200 small launches: standardise, scale, split, pack for the
+        # forward and the data-gradient convs) is captured once into a HIP graph and replayed: same buffers, one launch
+        self._repack_graph = None if os.environ.get('DMH_TRAIN_GRAPH', '1') != '0' else False
 
     # ---- forward + backward of GaussianDiffusion.forward (CFG:808-842) on one 12-channel batch
     def loss_and_grads(self, img, classes, t=None, noise=None, keep=None, grad_scale=1.0):
@@ -546,15 +552,31 @@ class TrainStep:
         """clip by global norm, Adam, bump the weight epoch (the sampling engine and UnetTrain re-pack on it)."""
         names = [k for k in self.params if k in grads]
         gl = [grads[k].contiguous() for k in names]
-        clip = ops.grad_norm_clip(gl, self.max_grad_norm)
         self.opt_step += 1
-        for k, gr in zip(names, gl):
-            ops.adam_(self.params[k].data, gr, self.m[k], self.v[k], clip, self.lr, self.betas[0], self.betas[1],
-                      self.eps, self.opt_step)
+        clip = ops.clip_adam_multi_([self.params[k].data for k in names], gl, [self.m[k] for k in names],
+                                    [self.v[k] for k in names], self.max_grad_norm, self.lr, self.betas[0], self.betas[1],
+                                    self.eps, self.opt_step)
         self.unet._dmh_epoch = getattr(self.unet, '_dmh_epoch', 0) + 1
-        self.ut.refresh()
+        self.refresh()
         self.last_norm = clip
         return clip
+
+    def refresh(self):
+        """re-pack the training kernels' weight images from the (updated / loaded) parameters"""
+        if self._repack_graph is None:
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.ut.refresh()
+                self._repack_graph = g
+            except Exception as e:                         # capture not available: stay on plain launches
+                print(f'dmhomo_amd: HIP graph capture of the weight re-pack failed ({e}); using plain launches')
+                self._repack_graph = False
+        if self._repack_graph is False:
+            self.ut.refresh()
+        else:
+            self._repack_graph.replay()
 
     def step(self, batches, draws=None):
         """``batches``: ``accum`` pairs (12-channel batch, classes).  -> summed (loss / accum) like DDP:1849."""

@@ -303,6 +303,13 @@ int dmh_gradnorm_finalize(const double* part, int n, float max_norm, float* norm
 int dmh_adam(float* p, const float* g, float* m, float* v, const float* gscale, int64_t n, float lr, float b1, float b2,
              float eps, int step, void* stream);
 int dmh_ema(float* ema, const float* p, int64_t n, float decay, void* stream);
+/* multi-tensor forms of the two above: p / g / m / v / n are HOST arrays of ``count`` device pointers / element counts
+ * (the ~280 parameter tensors of the UNet go out in count/48 launches); part: f64 [dmh_multi_blocks(n, count)], to be
+ * reduced by dmh_gradnorm_finalize */
+int64_t dmh_multi_blocks(const int64_t* n, int count);
+int dmh_sumsq_multi(const float* const* g, const int64_t* n, int count, double* part, void* stream);
+int dmh_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n, int count,
+                   const float* gscale, float lr, float b1, float b2, float eps, int step, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------

@@ -83,7 +83,7 @@ def main():
     line = {'metric': 'training images/sec (128x128, optimiser step incl. clip + Adam + weight re-pack)',
             'value': a.bs * a.accum * world / dt, 'unit': 'images/s', 'n_gpus': world, 'ms_per_step': dt * 1e3,
             'config': {'workload': f'DGM Unet dim={a.dim}, {a.size}x{a.size}, {a.bs} images/GPU x accum {a.accum}',
-                       'arithmetic': 'fp32 tensors; f16x3 split products forward and dgrad, fp32 MFMA wgrad'},
+                       'arithmetic': 'fp32 tensors; fp16-piece (3 MFMAs per product block) forward, data-gradient and 3x3 weight-gradient convolutions, exact-fp32 MFMA for the 1x1 / 7x7 weight gradients and the small GEMMs'},
             'split_ms': {'forward_backward': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
                          'clip_adam_repack': ev[2].elapsed_time(ev[3])},
             'loss': float(loss)}
