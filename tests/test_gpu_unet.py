@@ -140,6 +140,11 @@ def test_fullsize_rows_independent_and_cfg_modes_agree():
         m.cfg_mode = mode
         torch.manual_seed(5)          # the conditional pass draws its class-dropout mask (CFG:404 -> CFG:422), like the reference
         outs[mode] = m.forward_with_cond_scale(g(x), g(t), g(c), g(rf), g(mk), cond_scale=3.).clone()
+    m.cfg_mode, m.dedup_dropped_rows = 'batched', True     # opt-in: dropped rows of the conditional pass computed once
+    torch.manual_seed(5)
+    outs['dedup'] = m.forward_with_cond_scale(g(x), g(t), g(c), g(rf), g(mk), cond_scale=3.).clone()
+    m.dedup_dropped_rows = False
+    assert torch.equal(outs['batched'], outs['dedup'])
     assert torch.isfinite(outs['batched']).all()
     assert torch.equal(outs['batched'], outs['streams'])
 
