@@ -361,7 +361,17 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         return ops.loss_combine(loss, photo, w)
 
     def forward(self, img, *args, **kwargs):
-        """CFG:808-842: split the 12-channel batch (DDP:1162 layout), draw t, evaluate p_losses (forward value)."""
+        """CFG:808-842: split the 12-channel batch (DDP:1162 layout), draw t, evaluate p_losses.
+
+        With autograd enabled and trainable parameters the returned loss carries a grad_fn: ``loss.backward()`` fills
+        ``parameter.grad`` exactly as the reference's does, so a user-written loop (``loss = diffusion(batch,
+        classes=c); loss.backward(); opt.step()``, DDP:1843-1857) runs unchanged — the gradients come from the HIP
+        backward kernels of dmhomo_amd.train (no autograd graph inside), computed together with the loss.  Under
+        ``torch.no_grad()`` only the value is evaluated."""
+        classes = kwargs.get('classes', args[0] if args else None)
+        if torch.is_grad_enabled() and classes is not None and any(p.requires_grad for p in self.model.parameters()):
+            from .train import loss_with_grad_fn
+            return loss_with_grad_fn(self, img, classes)
         b, c, h, w = img.shape
         assert h == self.image_size and w == self.image_size, f'height and width of image must be {self.image_size}'
         t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()

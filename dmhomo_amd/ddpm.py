@@ -253,7 +253,12 @@ def _clone_without_engine_caches(model):
         if eng is not None:
             memo[id(eng)] = None
             engines.append(eng)
+        ts = mod.__dict__.get('_dmh_train_step')          # training kernels' state (packed weights, a HIP graph): not copied
+        if ts is not None:
+            memo[id(ts)] = None
     new = copy.deepcopy(model, memo)
+    for mod in new.modules():
+        mod.__dict__.pop('_dmh_train_step', None)
     it = iter(engines)
     for mod in new.modules():
         if '_engine' in mod.__dict__:
@@ -444,6 +449,7 @@ class Trainer(object):
             from .train import TrainStep
             self._ts = TrainStep(self.model, lr=self.train_lr, betas=self.adam_betas,
                                  accum=self.gradient_accumulate_every)
+            self.model.__dict__['_dmh_train_step'] = self._ts     # ``self.model(batch, classes=...)`` shares its packs
             if self._opt_state is not None:
                 self._ts.load_state_dict(self._opt_state)
         return self._ts

@@ -469,13 +469,36 @@ class TrainStep:
         for k, p in self.params.items():
             assert p.dtype == torch.float32 and p.is_contiguous(), k
         self.ut = UnetTrain(self.unet, groups)
-        self.m = {k: torch.zeros_like(p) for k, p in self.params.items()}
-        self.v = {k: torch.zeros_like(p) for k, p in self.params.items()}
+        self._m = self._v = None          # Adam moments: allocated by the first optimiser step (apply / load_state_dict)
+        self._sig = self._signature()
         self.opt_step = 0
         self.last_norm = None
         # the weight re-pack after every optimiser step (~1200 small launches: standardise, scale, split, pack for the
         # forward and the data-gradient convs) is captured once into a HIP graph and replayed: same buffers, one launch
         self._repack_graph = None if os.environ.get('DMH_TRAIN_GRAPH', '1') != '0' else False
+
+    @property
+    def m(self):
+        if self._m is None:
+            self._m = {k: torch.zeros_like(p) for k, p in self.params.items()}
+        return self._m
+
+    @property
+    def v(self):
+        if self._v is None:
+            self._v = {k: torch.zeros_like(p) for k, p in self.params.items()}
+        return self._v
+
+    def _signature(self):
+        return tuple((p.data_ptr(), p._version) for p in self.params.values())
+
+    def ensure_fresh(self):
+        """re-pack when something other than ``apply`` changed the parameters (an external optimiser, load_state_dict)"""
+        sig = self._signature()
+        if sig != self._sig:
+            self.unet._dmh_epoch = getattr(self.unet, '_dmh_epoch', 0) + 1
+            self.refresh()
+            self._sig = sig
 
     # ---- forward + backward of GaussianDiffusion.forward (CFG:808-842) on one 12-channel batch
     def loss_and_grads(self, img, classes, t=None, noise=None, keep=None, grad_scale=1.0):
@@ -485,6 +508,7 @@ class TrainStep:
         df = self.diffusion
         b, c, h, w = img.shape
         assert h == df.image_size and w == df.image_size, f'height and width of image must be {df.image_size}'
+        self.ensure_fresh()
         dev = img.device
         if t is None:
             t = torch.randint(0, df.num_timesteps, (b,), device=dev).long()
@@ -591,3 +615,29 @@ class TrainStep:
         acc = self._allreduce_mean(acc)
         self.apply(acc)
         return total
+
+
+class _PLoss(torch.autograd.Function):
+    """autograd boundary of GaussianDiffusion.forward: the loss and every parameter gradient are produced together by
+    TrainStep.loss_and_grads (HIP kernels, manual tape); backward() just hands the gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, ts, img, classes, *params):
+        loss, grads = ts.loss_and_grads(img, classes)
+        ctx.grads = [grads.get(k) for k in ts.params]
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        s = float(gout)
+        out = [None if g is None else (g if s == 1.0 else ops.affine(g, s, 0.)) for g in ctx.grads]
+        ctx.grads = None
+        return (None, None, None, *out)
+
+
+def loss_with_grad_fn(diffusion, img, classes):
+    ts = diffusion.__dict__.get('_dmh_train_step')
+    if ts is None:
+        ts = TrainStep(diffusion)
+        diffusion.__dict__['_dmh_train_step'] = ts        # not a submodule / parameter: plain attribute
+    return _PLoss.apply(ts, img, classes, *ts.params.values())

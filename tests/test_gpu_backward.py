@@ -407,3 +407,45 @@ def test_trainer_train_loop_and_checkpoint(golden_dir, tmp_path):
     assert ts2.opt_step == 4 and torch.equal(ts2.m['init_conv.weight'], tr.train_step_engine().m['init_conv.weight'])
     tr2.train()
     assert tr2.step == 5
+
+
+def test_user_loop_loss_backward_and_torch_optimizer(golden_dir):
+    """the reference's own loop shape (DDP:1843-1857) written by a user: loss = diffusion(batch, classes=c);
+    loss.backward(); clip_grad_norm_; torch.optim.Adam.step() — the loss carries a grad_fn whose gradients are the HIP
+    backward kernels'; an external optimiser's in-place update is noticed (weights re-packed) on the next call"""
+    gd, m, d, ts, img, classes, draws = _train_setup(golden_dir)
+    opt = torch.optim.Adam(d.parameters(), lr=1e-3, betas=(0.9, 0.99))
+
+    class Fixed:                                   # replay the golden draws through the module's own RNG hooks
+        def randn(self, shape, device):
+            return draws['noise']
+
+        def uniform(self, n, device):
+            return torch.where(draws['keep'].bool(), 0.25, 0.75)
+
+    d.rng = m.rng = Fixed()
+    want_t = draws['t']
+    orig = torch.randint
+    torch.randint = lambda *a, **k: want_t          # CFG:812 draws t with torch.randint
+    try:
+        losses = []
+        for i in range(3):
+            loss = d(img, classes=classes)
+            assert loss.requires_grad and loss.grad_fn is not None
+            loss.backward()
+            if i == 0:
+                ref = torch.from_numpy(gd['grad.init_conv.weight'])
+                got = m.init_conv.weight.grad.cpu()
+                assert ((got - ref).abs().max() / ref.abs().max()).item() < 1e-4
+                assert abs(float(loss) - float(gd['loss'])) < 2e-5 * float(gd['loss'])
+            torch.nn.utils.clip_grad_norm_(d.parameters(), 1.0)
+            opt.step()
+            opt.zero_grad()
+            losses.append(float(loss))
+        with torch.no_grad():
+            val = d(img, classes=classes)
+        assert not val.requires_grad
+    finally:
+        torch.randint = orig
+    print('[parity] user loop losses', losses)
+    assert losses[2] < losses[1] < losses[0]
