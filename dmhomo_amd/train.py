@@ -591,7 +591,8 @@ class TrainStep:
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: other threads of the process (e.g. the RCCL watchdog) may keep calling into HIP meanwhile
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self.ut.refresh()
                 self._repack_graph = g
             except Exception as e:                         # capture not available: stay on plain launches

@@ -80,7 +80,7 @@ def main():
     ts.apply(acc)
     ev[3].record()
     torch.cuda.synchronize()
-    line = {'metric': 'training images/sec (128x128, optimiser step incl. clip + Adam + weight re-pack)',
+    line = {'metric': f'training images/sec ({a.size}x{a.size}, optimiser step incl. clip + Adam + weight re-pack)',
             'value': a.bs * a.accum * world / dt, 'unit': 'images/s', 'n_gpus': world, 'ms_per_step': dt * 1e3,
             'config': {'workload': f'DGM Unet dim={a.dim}, {a.size}x{a.size}, {a.bs} images/GPU x accum {a.accum}',
                        'arithmetic': 'fp32 tensors; fp16-piece (3 MFMAs per product block) forward, data-gradient and 3x3 weight-gradient convolutions, exact-fp32 MFMA for the 1x1 / 7x7 weight gradients and the small GEMMs'},
