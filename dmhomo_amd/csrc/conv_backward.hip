@@ -177,7 +177,7 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 
 namespace {
-template <int KH>
+template <int KH, int NCBW>
 struct WhCfg {
   static constexpr int NT = KH * KH;
   static constexpr int XH = TH + KH - 1, XW = TW + KH - 1;
@@ -185,9 +185,11 @@ struct WhCfg {
   static constexpr int XROWB = ((XW + 7) / 8 * 8) * 2;          // bytes per halo row (pixels padded to 8)
   static constexpr int XPITCH = ((XH * XROWB / 16) | 1) * 16;   // bytes per input channel: an odd number of 16-byte units
   static constexpr int APITCH = TP * 2 + 16;                    // bytes per output channel: 64 px
-  static constexpr int A_BYTES = 64 * APITCH, X_BYTES = 16 * XPITCH;
+  static constexpr int A_BYTES = 64 * APITCH, X_BYTES = 16 * NCBW * XPITCH;
   static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * X_BYTES + 64;   // planes + the maxima slots
-  static constexpr int XSLOTS = XH * XG * 4;                    // X staging slots (4 px x 4 c each) per item, <= 256
+  static constexpr int XQN = 4 * NCBW;                          // channel quads of the workgroup's input channels
+  static constexpr int XSLOTS = XH * XG * XQN;                  // X staging slots (4 px x 4 c each) per item, <= 256
+  static constexpr int OBG = 4 / NCBW;                          // wave -> (output-block group, local channel block)
 };
 __device__ __forceinline__ float amax4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
 __device__ __forceinline__ int max_exponent(unsigned bits) {  // v in [2^e, 2^(e+1)); all-zero / tiny tiles clamp at -100
@@ -201,9 +203,10 @@ __device__ __forceinline__ int max_exponent(unsigned bits) {  // v in [2^e, 2^(e
 // quarter of the accumulators of the fp32 kernel (9 x 4 registers for 3x3), so four workgroups fit a CU and hide each
 // other's staging, and a pixel split costs a quarter of the partial block.  dY is staged by all four channel-block
 // workgroups of a pair (they share a split index modulo 8, hence an XCD and its L2).
-template <int KH, int PAD>
-__global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
-  using Cfg = WhCfg<KH>;
+template <int KH, int PAD, int NCBW>
+__global__ __launch_bounds__(256, NCBW == 1 ? 4 : 2) void conv_wgrad_f16x3_kernel(WgArgs p) {
+  using Cfg = WhCfg<KH, NCBW>;
+  constexpr int OBW = NCBW, OBG = Cfg::OBG;  // output blocks per wave; waves per channel block
   constexpr int NT = Cfg::NT, XW = Cfg::XW, XG = Cfg::XG, XROWB = Cfg::XROWB, XPITCH = Cfg::XPITCH, APITCH = Cfg::APITCH;
   extern __shared__ __attribute__((aligned(16))) char ldsb[];
   char* a1 = ldsb;
@@ -215,15 +218,18 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
   const int split = blockIdx.x;
-  const int pair = blockIdx.y >> 2, cbq = blockIdx.y & 3, ot = pair / p.ctiles, ct = pair % p.ctiles;
-  const int o0 = ot * 64, c0 = ct * 64 + cbq * 16;
+  const int pair = blockIdx.y / OBG, cbq = blockIdx.y % OBG, ot = pair / p.ctiles, ct = pair % p.ctiles;
+  const int o0 = ot * 64, c0 = ct * 64 + cbq * 16 * NCBW;
+  const int obg = wave % OBG, cbl = wave / OBG;  // this wave: output blocks obg*OBW .. +OBW-1, local channel block cbl
   const int Cin = p.C0 + p.C1;
   const int Hv = p.ups ? p.Hin * 2 : p.Hin, Wv = p.ups ? p.Win * 2 : p.Win;
   if (c0 >= Cin) return;  // a channel block beyond the input channels (Cin not a multiple of 64): its slice stays unread
 
-  float4v acc[NT];
+  float4v acc[OBW][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = float4v{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < OBW; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = float4v{0.f, 0.f, 0.f, 0.f};
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);  // this thread's 4 output channels, summed over its pixels
   int ed = -127, ex = -127;                        // running exponents of the maxima
   if (tid < 4) mx[tid] = 0u;
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
   const int per = (p.nitems + p.nsplit - 1) / p.nsplit;
   const int i0 = split * per, i1 = min(i0 + per, p.nitems);
   const int q4 = tid & 15, pg = tid >> 4;  // dY staging: channel quad, pixel group
-  const int xq = tid & 3, xgi = tid >> 2;  // X staging: channel quad (of this block's 4), (row, pixel group)
+  const int xq = tid % Cfg::XQN, xgi = tid / Cfg::XQN;  // X staging: channel quad of this workgroup's, (row, pixel group)
   const int xrow = xgi / XG, xg = xgi % XG;
   const bool xslot = tid < Cfg::XSLOTS;
 
@@ -306,7 +312,9 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
     if (nd + nx != ed + ex) {  // workgroup-uniform
       const float f = ldexpf(1.f, max((ed + ex) - (nd + nx), -120));
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] *= f;
+      for (int i = 0; i < OBW; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[i][t] *= f;
       ed = nd;
       ex = nx;
     }
@@ -349,13 +357,17 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
     if (!(p.ablate & 1))
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const char* ap = a1 + (wave * 16 + l15) * APITCH + (kg * TW + half * 8) * 2;
-        const half8 d1 = *reinterpret_cast<const half8*>(ap);
-        const half8 d2 = *reinterpret_cast<const half8*>(ap + Cfg::A_BYTES);
-        const half8 d1s = d1 * (_Float16)(1.0f / 2048.0f);
+        half8 d1[OBW], d2[OBW], d1s[OBW];
+#pragma unroll
+        for (int i = 0; i < OBW; ++i) {
+          const char* ap = a1 + ((obg * OBW + i) * 16 + l15) * APITCH + (kg * TW + half * 8) * 2;
+          d1[i] = *reinterpret_cast<const half8*>(ap);
+          d2[i] = *reinterpret_cast<const half8*>(ap + Cfg::A_BYTES);
+          d1s[i] = d1[i] * (_Float16)(1.0f / 2048.0f);
+        }
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
-          const char* xp = x1 + l15 * XPITCH + (kg + ky) * XROWB + half * 16;
+          const char* xp = x1 + (cbl * 16 + l15) * XPITCH + (kg + ky) * XROWB + half * 16;
           const uint4v u1 = *reinterpret_cast<const uint4v*>(xp);
           const uint4v u2 = *reinterpret_cast<const uint4v*>(xp + Cfg::X_BYTES);
           unsigned e1 = 0u, e2 = 0u;
@@ -381,14 +393,20 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
           }
           // the three terms, each across the kx accumulators: consecutive MFMAs never share an accumulator
 #pragma unroll
-          for (int kx = 0; kx < KH; ++kx)
-            acc[ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1s, b2[kx], acc[ky * KH + kx], 0, 0, 0);
+          for (int i = 0; i < OBW; ++i)
 #pragma unroll
-          for (int kx = 0; kx < KH; ++kx)
-            acc[ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2, b1[kx], acc[ky * KH + kx], 0, 0, 0);
+            for (int kx = 0; kx < KH; ++kx)
+              acc[i][ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1s[i], b2[kx], acc[i][ky * KH + kx], 0, 0, 0);
 #pragma unroll
-          for (int kx = 0; kx < KH; ++kx)
-            acc[ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, b1[kx], acc[ky * KH + kx], 0, 0, 0);
+          for (int i = 0; i < OBW; ++i)
+#pragma unroll
+            for (int kx = 0; kx < KH; ++kx)
+              acc[i][ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2[i], b1[kx], acc[i][ky * KH + kx], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < OBW; ++i)
+#pragma unroll
+            for (int kx = 0; kx < KH; ++kx)
+              acc[i][ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1[i], b1[kx], acc[i][ky * KH + kx], 0, 0, 0);
         }
       }
   }
@@ -396,13 +414,15 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
   // ---- partial block, un-scaled.  Layout [tap][channel block][wave][kg][l15][r]: one 16-byte store per lane, 1 KB
   // contiguous per wave (conv_wgrad_reduce_v2_kernel undoes the permutation while it writes the 147 KB of dW)
   const float osc = ldexpf(1.f, max(ed + ex - 28, -126));
-  float* pw = p.part_w + ((size_t)(split * (gridDim.y >> 2) + pair) * 64 * 64) * NT;
+  float* pw = p.part_w + ((size_t)(split * (gridDim.y / OBG) + pair) * 64 * 64) * NT;
   if (!(p.ablate & 8))
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      float4v v = acc[t] * osc;
-      *reinterpret_cast<float4v*>(pw + ((size_t)((t * 4 + cbq) * 4 + wave) * 4 + kg) * 64 + l15 * 4) = v;
-    }
+    for (int i = 0; i < OBW; ++i)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        float4v v = acc[i][t] * osc;
+        *reinterpret_cast<float4v*>(pw + ((size_t)((t * 4 + cbq * NCBW + cbl) * 4 + obg * OBW + i) * 4 + kg) * 64 + l15 * 4) = v;
+      }
   if (ct == 0 && cbq == 0) {  // bias partial: the 16 pixel groups of a channel quad -> one sum per output channel, fixed order
     __syncthreads();
     float* br = reinterpret_cast<float*>(a1);  // [16 pg][64 o]
@@ -412,7 +432,7 @@ __global__ __launch_bounds__(256, 4) void conv_wgrad_f16x3_kernel(WgArgs p) {
       float sb = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) sb += br[g * 64 + tid];
-      p.part_b[((size_t)split * ((gridDim.y >> 2) / p.ctiles) + ot) * 64 + tid] = sb;
+      p.part_b[((size_t)split * ((gridDim.y / OBG) / p.ctiles) + ot) * 64 + tid] = sb;
     }
   }
 }
@@ -559,8 +579,17 @@ static int wgrad_splits(int nitems, int npairs) {
 }
 // fp16-piece kernels: about 1024 workgroups (4 per CU) over (splits, pairs * 4 channel blocks); splits a multiple of 8 where
 // possible so that the four channel-block workgroups of a pair share an XCD (linear workgroup id modulo 8)
+static int wgrad_ncbw() {  // input-channel blocks per workgroup of the fp16-piece kernels (DMH_WGRAD_NCBW=1|2)
+  static const int v = [] {
+    const char* e = getenv("DMH_WGRAD_NCBW");
+    const int k = e ? atoi(e) : 2;
+    return k == 1 ? 1 : 2;
+  }();
+  return v;
+}
 static int wgrad_splits_f16(int nitems, int npairs) {
-  int s = 1024 / (4 * (npairs > 0 ? npairs : 1));
+  const int ncbw = wgrad_ncbw();
+  int s = (ncbw == 1 ? 1024 : 512) / ((4 / ncbw) * (npairs > 0 ? npairs : 1));
   if (s >= 8) s = s / 8 * 8;
   if (s < 1) s = 1;
   if (s > nitems) s = nitems;
@@ -593,10 +622,10 @@ static void launch_wgrad(const WgArgs& a, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, a);
 }
 
-template <int KH, int PAD>
+template <int KH, int PAD, int NCBW>
 static void launch_wgrad_f16(const WgArgs& a, dim3 grid, hipStream_t st) {
-  using Cfg = WhCfg<KH>;
-  auto kern = conv_wgrad_f16x3_kernel<KH, PAD>;
+  using Cfg = WhCfg<KH, NCBW>;
+  auto kern = conv_wgrad_f16x3_kernel<KH, PAD, NCBW>;
   if (Cfg::LDS_BYTES > 64 * 1024) {
     static bool attr = false;
     if (!attr) {
@@ -652,11 +681,12 @@ extern "C" int dmh_conv_wgrad(const float* dy, const float* src0, const float* s
   a.part_w = work;
   a.part_b = work + (int64_t)a.nsplit * npairs * 64 * 64 * KH * KH;
   if (f16) {
-    dim3 grid(a.nsplit, npairs * 4);
-    switch (KH) {
-      case 1: launch_wgrad_f16<1, 0>(a, grid, st); break;
-      case 2: launch_wgrad_f16<2, 0>(a, grid, st); break;
-      default: launch_wgrad_f16<3, 1>(a, grid, st); break;
+    if (wgrad_ncbw() == 1) {
+      dim3 grid(a.nsplit, npairs * 4);
+      if (KH == 2) launch_wgrad_f16<2, 0, 1>(a, grid, st); else launch_wgrad_f16<3, 1, 1>(a, grid, st);
+    } else {
+      dim3 grid(a.nsplit, npairs * 2);
+      if (KH == 2) launch_wgrad_f16<2, 0, 2>(a, grid, st); else launch_wgrad_f16<3, 1, 2>(a, grid, st);
     }
     DMH_CHECK_LAUNCH("dmh_conv_wgrad");
     const int64_t units = (int64_t)npairs * KH * KH * 1024;
