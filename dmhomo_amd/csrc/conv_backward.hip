@@ -204,7 +204,7 @@ __device__ __forceinline__ int max_exponent(unsigned bits) {  // v in [2^e, 2^(e
 // other's staging, and a pixel split costs a quarter of the partial block.  dY is staged by all four channel-block
 // workgroups of a pair (they share a split index modulo 8, hence an XCD and its L2).
 template <int KH, int PAD, int NCBW>
-__global__ __launch_bounds__(256, NCBW == 1 ? 4 : 2) void conv_wgrad_f16x3_kernel(WgArgs p) {
+__global__ __launch_bounds__(256, NCBW == 1 ? 3 : 2) void conv_wgrad_f16x3_kernel(WgArgs p) {
   using Cfg = WhCfg<KH, NCBW>;
   constexpr int OBW = NCBW, OBG = Cfg::OBG;  // output blocks per wave; waves per channel block
   constexpr int NT = Cfg::NT, XW = Cfg::XW, XG = Cfg::XG, XROWB = Cfg::XROWB, XPITCH = Cfg::XPITCH, APITCH = Cfg::APITCH;
@@ -242,50 +242,63 @@ __global__ __launch_bounds__(256, NCBW == 1 ? 4 : 2) void conv_wgrad_f16x3_kerne
   const int xrow = xgi / XG, xg = xgi % XG;
   const bool xslot = tid < Cfg::XSLOTS;
 
-  for (int item = i0; item < i1; ++item) {
-    const int par = (item - i0) & 1;
+  // Staging registers of one item: raw loads (issued from clamped addresses, so that they can fly during the previous
+  // item's MFMA phase — hipcc drains vmcnt around loads that sit behind a branch) + validity bits applied on use.
+  float4 dv[4], xv[4], pa, pb;
+  unsigned vmask = 0u;  // bit j: dv[j] valid; bit 4+j: xv[j] valid; bit 8: xv takes the GroupNorm+SiLU prologue
+  auto issue_loads = [&](int item) {
     const int tx = item % p.tilesX, ty = (item / p.tilesX) % p.tilesY, b = item / (p.tilesX * p.tilesY);
     const int oy0 = ty * TH, ox0 = tx * TW;
-    // ---- global -> registers: dY, 4 px x 4 o per thread
-    float4 dv[4];
+    unsigned vm = 0u;
     {
       const int y = oy0 + (pg >> 2), o = o0 + q4 * 4;
+      const int yc = min(y, p.H - 1), oc = min(o, p.Cout - 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int x = ox0 + (pg & 3) * 4 + j;
-        dv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(p.ablate & 2) && y < p.H && x < p.W && o < p.Cout)
-          dv[j] = ld4(p.dy + ((size_t)(b * p.H + y) * p.W + x) * p.Cout + o);
+        if (y < p.H && x < p.W && o < p.Cout) vm |= 1u << j;
+        dv[j] = ld4(p.dy + ((size_t)(b * p.H + yc) * p.W + min(x, p.W - 1)) * p.Cout + oc);
       }
     }
-    // ---- X halo, 4 px x 4 c per slot (the conv's input as it saw it: concat, GroupNorm+SiLU prologue, x2 upsampling)
-    float4 xv[4];
     {
-      const int c = c0 + xq * 4;
-      const int y = oy0 - PAD + xrow;
+      const int c = c0 + xq * 4, cc = min(c, Cin - 4);
+      const int y = oy0 - PAD + xrow, yc = min(max(y, 0), Hv - 1);
+      const int sy = p.ups ? (yc >> 1) : yc;
+      const bool first = cc < p.C0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int xl = xg * 4 + j, x = ox0 - PAD + xl;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(p.ablate & 2) && xslot && xl < XW && y >= 0 && y < Hv && x >= 0 && x < Wv && c < Cin) {
-          const int sy = p.ups ? (y >> 1) : y, sx = p.ups ? (x >> 1) : x;
-          const size_t pixoff = (size_t)(b * p.Hin + sy) * p.Win + sx;
-          if (c < p.C0) {
-            v = ld4(p.src0 + pixoff * p.C0 + c);
-            if (p.in_coef) {
-              const float4 a = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + c);
-              const float4 bb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + c);
-              v.x = silu_f(fmaf(a.x, v.x, bb.x));
-              v.y = silu_f(fmaf(a.y, v.y, bb.y));
-              v.z = silu_f(fmaf(a.z, v.z, bb.z));
-              v.w = silu_f(fmaf(a.w, v.w, bb.w));
-            }
-          } else {
-            v = ld4(p.src1 + pixoff * p.C1 + (c - p.C0));
-          }
-        }
-        xv[j] = v;
+        if (xslot && xl < XW && y >= 0 && y < Hv && x >= 0 && x < Wv && c < Cin) vm |= 16u << j;
+        const int xc = min(max(x, 0), Wv - 1), sx = p.ups ? (xc >> 1) : xc;
+        const size_t pixoff = (size_t)(b * p.Hin + sy) * p.Win + sx;
+        const float* src = first ? p.src0 + pixoff * p.C0 + cc : p.src1 + pixoff * p.C1 + (cc - p.C0);
+        xv[j] = ld4(src);
       }
+      const int cp = min(cc, p.C0 - 4);
+      const float* cf = p.in_coef ? p.in_coef + (size_t)(b * 2) * p.C0 + cp : p.src0;
+      pa = ld4(cf);
+      pb = ld4(cf + (p.in_coef ? p.C0 : 0));
+      if (p.in_coef && first) vm |= 256u;
+    }
+    vmask = vm;
+  };
+  if (i0 < i1) issue_loads(i0);
+
+  for (int item = i0; item < i1; ++item) {
+    const int par = (item - i0) & 1;
+    // ---- the staged registers become values: zero outside the image / channels, the consumer-side prologue
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!(vmask & (1u << j)) || (p.ablate & 2)) dv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v = xv[j];
+      if (vmask & 256u) {
+        v.x = silu_f(fmaf(pa.x, v.x, pb.x));
+        v.y = silu_f(fmaf(pa.y, v.y, pb.y));
+        v.z = silu_f(fmaf(pa.z, v.z, pb.z));
+        v.w = silu_f(fmaf(pa.w, v.w, pb.w));
+      }
+      if (!(vmask & (16u << j)) || (p.ablate & 2)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      xv[j] = v;
     }
     // ---- tile maxima -> LDS (non-negative floats order like their bit patterns)
     float md = 0.f, mxx = 0.f;
@@ -353,6 +366,8 @@ __global__ __launch_bounds__(256, NCBW == 1 ? 4 : 2) void conv_wgrad_f16x3_kerne
       }
     }
     __syncthreads();  // (B) tiles staged
+    issue_loads(min(item + 1, i1 - 1));  // the next item's pixels fly during this item's matrix phase
+    __builtin_amdgcn_sched_barrier(0);
     // ---- 2 K steps of 32 pixels (4 tile rows x 8 pixels of a half row)
     if (!(p.ablate & 1))
 #pragma unroll
