@@ -619,7 +619,7 @@ extern "C" int64_t dmh_conv_wgrad_workspace_floats(int B, int H, int W, int C0, 
   const int npairs = cdiv(Cout, 64) * cdiv(C0 + C1, wgrad_cw(KH));
   const int nitems = B * cdiv(H, TH) * cdiv(W, TW);
   int ns = wgrad_splits(nitems, npairs);
-  if ((KH == 2 || KH == 3) && wgrad_splits_f16(nitems, npairs) > ns) ns = wgrad_splits_f16(nitems, npairs);
+  if (KH <= 3 && wgrad_splits_f16(nitems, npairs) > ns) ns = wgrad_splits_f16(nitems, npairs);
   return (int64_t)ns * npairs * 64 * 64 * KH * KH + (int64_t)ns * cdiv(Cout, 64) * 64;
 }
 
@@ -691,7 +691,11 @@ extern "C" int dmh_conv_wgrad(const float* dy, const float* src0, const float* s
     const char* e = getenv("DMH_WGRAD_VARIANT");
     return e ? atoi(e) : 1;
   }();
-  const bool f16 = variant == 1 && (KH == 2 || KH == 3);  // 1x1: too little matrix work per staged dY tile, the fp32 kernel wins
+  static const int f16_1x1 = [] {
+    const char* e = getenv("DMH_WGRAD_F16_1X1");
+    return e ? atoi(e) : 0;
+  }();
+  const bool f16 = variant == 1 && (KH == 2 || KH == 3 || (KH == 1 && f16_1x1));  // 1x1: too little matrix work per staged dY tile, the fp32 kernel wins
   a.nsplit = f16 ? wgrad_splits_f16(a.nitems, npairs) : wgrad_splits(a.nitems, npairs);
   a.part_w = work;
   a.part_b = work + (int64_t)a.nsplit * npairs * 64 * 64 * KH * KH;
@@ -701,7 +705,9 @@ extern "C" int dmh_conv_wgrad(const float* dy, const float* src0, const float* s
       if (KH == 2) launch_wgrad_f16<2, 0, 1>(a, grid, st); else launch_wgrad_f16<3, 1, 1>(a, grid, st);
     } else {
       dim3 grid(a.nsplit, npairs * 2);
-      if (KH == 2) launch_wgrad_f16<2, 0, 2>(a, grid, st); else launch_wgrad_f16<3, 1, 2>(a, grid, st);
+      if (KH == 1) launch_wgrad_f16<1, 0, 2>(a, grid, st);
+      else if (KH == 2) launch_wgrad_f16<2, 0, 2>(a, grid, st);
+      else launch_wgrad_f16<3, 1, 2>(a, grid, st);
     }
     DMH_CHECK_LAUNCH("dmh_conv_wgrad");
     const int64_t units = (int64_t)npairs * KH * KH * 1024;
