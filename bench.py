@@ -98,7 +98,19 @@ def main():
     ap.add_argument('--cfg-mode', default='streams', choices=['batched', 'streams'])
     ap.add_argument('--stream-splits', type=int, default=1, help="row sub-batches per CFG pass in 'streams' mode")
     ap.add_argument('--no-conv-events', action='store_true', help='skip the per-launch HIP events')
+    ap.add_argument('--workload', default='sample', choices=['sample', 'train'],
+                    help="'train': the optimiser step of BASELINE configs[3] (16 images per GPU, gradients averaged over "
+                         "RCCL) instead of the headline sampling loop; same launch contract, see tools/train_bench.py")
     args = ap.parse_args()
+    if args.workload == 'train':
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import train_bench
+        ns = argparse.Namespace(bs=16 if args.bs == 25 else args.bs, size=args.image_size, dim=args.dim, steps=args.steps,
+                                warmup=args.warmup, accum=1, torch=False)
+        line = train_bench.run(ns)
+        if line is not None:
+            print(json.dumps(line))
+        return
 
     import torch.distributed as dist
     from dmhomo_amd import cfg, ddpm, ops

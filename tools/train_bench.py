@@ -28,7 +28,13 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--accum', type=int, default=1)
     ap.add_argument('--torch', action='store_true')
-    a = ap.parse_args()
+    line = run(ap.parse_args())
+    if line is not None:
+        print(json.dumps(line))
+
+
+def run(a):
+    """-> the result dict on rank 0 (None elsewhere).  ``a``: namespace with bs, size, dim, steps, warmup, accum, torch"""
     from dmhomo_amd import cfg, train, distributed as D
     from dmhomo_amd.ddpm import SyntheticConditions
     rank, world = 0, 1
@@ -87,10 +93,11 @@ def main():
             'split_ms': {'forward_backward': ev[0].elapsed_time(ev[1]), 'allreduce': ev[1].elapsed_time(ev[2]),
                          'clip_adam_repack': ev[2].elapsed_time(ev[3])},
             'loss': float(loss)}
+    line.update({'steps': a.steps, 'warmup': a.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                 'dtype': 'f32', 'data': 'synthetic'})
     if a.torch and rank == 0:
         line['torch_autograd_same_gpu'] = torch_leg(a, dev)
-    if rank == 0:
-        print(json.dumps(line))
+    return line if rank == 0 else None
 
 
 def torch_leg(a, dev):
