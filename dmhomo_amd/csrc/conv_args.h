@@ -18,6 +18,7 @@ struct ConvArgs {
   int B, Hin, Win, C0, C1, Cout, Hout, Wout;
   int nch0, nch1, tilesX, tilesY;
   int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
+  int xcd;     // 1: workgroup ids are re-dealt so that each XCD (id % 8) walks a contiguous run of tiles (DMH_CONV_XCD)
 };
 
 
@@ -46,6 +47,11 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
   a.tilesX = cdiv(Wout, TW);
   a.tilesY = cdiv(Hout, TH);
   a.ablate = 0;
+  static const int xcd = [] {
+    const char* e = getenv("DMH_CONV_XCD");
+    return e ? atoi(e) : 1;
+  }();
+  a.xcd = xcd;
   return a;
 }
 
@@ -153,7 +159,8 @@ struct EpilogueRows {
   // Stat tiles are 8 rows x 16 columns (= two waves along M) whatever the workgroup tile, so the tile count
   // does not depend on Cout: stats[b][stat tile][Cout][2] with stat tile = (ty * TH/8 + g) * tilesX + tx.
   template <int WM, int WN, int TH>
-  __device__ __forceinline__ void write_stats_grid(const ConvArgs& p, float* lds, int ty, int tx) {
+  __device__ __forceinline__ void write_stats_grid(const ConvArgs& p, float* lds, int ty, int tx, int by = -1) {
+    if (by < 0) by = blockIdx.y;  // (kernels that re-deal their workgroup ids pass the logical cout-tile index)
     if (!p.stats) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
 #pragma unroll
@@ -184,7 +191,7 @@ struct EpilogueRows {
     if (tid < 128) {
       const int q = tid >> 6, c = tid & 63;
       const int g = WN == 1 ? q : 0, wnq = WN == 1 ? 0 : q;
-      const int chan = (blockIdx.y * WN + wnq) * 64 + c;
+      const int chan = (by * WN + wnq) * 64 + c;
       const int srow = ty * (TH / 8) + g;
       if (chan < p.Cout && srow * 8 < p.Hout) {
         const int w0 = (g * 2 + 0) * WN + wnq, w1 = (g * 2 + 1) * WN + wnq;

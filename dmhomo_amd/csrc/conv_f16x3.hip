@@ -92,12 +92,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   const int l15 = lane & 15;  // fragment row (pixel) / column (output channel)
   const int wm = wave / WN, wn = wave % WN;
 
-  int t = blockIdx.x;
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2: re-deal the ids so that
+  // XCD k walks the k-th contiguous run of (cout tile, sample, tile row, tile column) — vertically adjacent tiles, whose
+  // halos overlap, then run at the same time on the same L2.
+  int t = blockIdx.x, by = blockIdx.y;
+  if (p.xcd) {
+    const int nb = gridDim.x, total = nb * gridDim.y, lin = t + by * nb;
+    const int q = total >> 3, r = total & 7, xcd = lin & 7, local = lin >> 3;
+    const int nl = xcd * q + min(xcd, r) + local;
+    t = nl % nb;
+    by = nl / nb;
+  }
   const int tx = t % p.tilesX;
   t /= p.tilesX;
   const int ty = t % p.tilesY;
   const int b = t / p.tilesY;
-  const int nt = blockIdx.y * WN + wn;
+  const int nt = by * WN + wn;
   const int n0 = nt * 64;
 
   const int oy0 = ty * TH, ox0 = tx * TW;
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     }
 #ifdef DMH_STAMPS
     STAMP(5)  // epilogue
-    if (p.stats && lane == 0 && blockIdx.y == 0) {
+    if (p.stats && lane == 0 && by == 0) {
       const int stiles = ((p.Hout + 7) / 8) * p.tilesX;
       unsigned long long* d = reinterpret_cast<unsigned long long*>(
                                   p.stats + ((size_t)(b * stiles + (ty * (TH / 8)) * p.tilesX + tx) * p.Cout) * 2) + wave * 8;
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       d[7] = __builtin_amdgcn_s_memrealtime() - rt_begin;
     }
 #else
-    er.template write_stats_grid<WM, WN, TH>(p, lds, ty, tx);
+    er.template write_stats_grid<WM, WN, TH>(p, lds, ty, tx, by);
 #endif
   }
 }
