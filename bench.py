@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--cfg-mode', default='streams', choices=['batched', 'streams'])
     ap.add_argument('--stream-splits', type=int, default=1, help="row sub-batches per CFG pass in 'streams' mode")
     ap.add_argument('--no-conv-events', action='store_true', help='skip the per-launch HIP events')
+    ap.add_argument('--variants', action='store_true',
+                    help='also time the opt-in dedup_dropped_rows mode (3 extra steps) and report it under "variants"')
     ap.add_argument('--workload', default='sample', choices=['sample', 'train'],
                     help="'train': the optimiser step of BASELINE configs[3] (16 images per GPU, gradients averaged over "
                          "RCCL) instead of the headline sampling loop; same launch contract, see tools/train_bench.py")
@@ -169,18 +171,19 @@ def main():
         log, ops.CONV_LOG = ops.CONV_LOG, None
         model.cfg_mode = args.cfg_mode
         roofline_mode = 'batched (extra untimed step)'
-    # ---- reported beside the headline, never as it: the opt-in de-duplication of the conditional pass's dropped rows
-    # (cfg.Unet.dedup_dropped_rows: identical outputs, B + kept rows per denoise step instead of 2B), 2 untimed-for-the-
-    # headline steps
-    model.cfg_mode, model.dedup_dropped_rows = 'batched', True
-    step()
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(2):
+    # ---- --variants: reported beside the headline, never as it: the opt-in de-duplication of the conditional pass's
+    # dropped rows (cfg.Unet.dedup_dropped_rows: identical outputs, B + kept rows per denoise step instead of 2B)
+    dedup_elapsed = 0.0
+    if args.variants:
+        model.cfg_mode, model.dedup_dropped_rows = 'batched', True
         step()
-    fence()
-    dedup_elapsed = (time.perf_counter() - t1) / 2
-    model.cfg_mode, model.dedup_dropped_rows = args.cfg_mode, False
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()
+        fence()
+        dedup_elapsed = (time.perf_counter() - t1) / 2
+        model.cfg_mode, model.dedup_dropped_rows = args.cfg_mode, False
     if world > 1:
         t = torch.tensor([elapsed, dedup_elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,11 +209,12 @@ def main():
                                      'fp32 accumulate, error at the fp32-accumulation level: DESIGN.md 3.1); '
                                      'DMH_CONV3_VARIANT=6 selects the exact-fp32 kernels'},
         }
-        res['variants'] = {'dedup_dropped_rows': {
-            'value': args.bs * world / dedup_elapsed, 'unit': 'images/s', 'ms_per_step': dedup_elapsed * 1e3,
-            'note': 'NOT the headline: opt-in cfg.Unet.dedup_dropped_rows — rows of the conditional pass whose class was '
-                    'dropped (p = 0.5, CFG:404) equal their null-pass rows and are computed once; bitwise identical samples '
-                    '(tests/test_gpu_unet.py::test_fullsize_rows_independent_and_cfg_modes_agree)'}}
+        if args.variants:
+            res['variants'] = {'dedup_dropped_rows': {
+                'value': args.bs * world / dedup_elapsed, 'unit': 'images/s', 'ms_per_step': dedup_elapsed * 1e3,
+                'note': 'NOT the headline: opt-in cfg.Unet.dedup_dropped_rows — rows of the conditional pass whose class '
+                        'was dropped (p = 0.5, CFG:404) equal their null-pass rows and are computed once; bitwise identical '
+                        'samples (tests/test_gpu_unet.py::test_fullsize_rows_independent_and_cfg_modes_agree)'}}
         if log:
             fl3 = ms3 = n3 = 0.0
             flc = msc = nc = 0.0
