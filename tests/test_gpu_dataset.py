@@ -12,12 +12,14 @@ from oracle import dataset as OD
 pytestmark = pytest.mark.gpu
 
 
-def _make_dataset(root, n=5, hw=(360, 640), seed=0):
+def _make_dataset(root, n=5, hw=(360, 640), seed=0, ragged=False):
     from PIL import Image
     rng = np.random.default_rng(seed)
     os.makedirs(os.path.join(root, 'HomoGAN_Bug_Masks'))
     labels, truth = {}, {}
+    hw0 = hw
     for i in range(n):
+        hw = (hw0[0] - 24 * (i % 3), hw0[1] - 40 * (i % 2)) if ragged else hw0      # mixed source sizes in one batch
         d = f'{i:04d}'
         os.makedirs(os.path.join(root, d), exist_ok=True)
         a, b = f'{d}_{10000 + i}', f'{d}_{10001 + i}'
@@ -62,6 +64,17 @@ def test_unhomo_train_data_vs_oracle(tmp_path, size):
     dl = ConditionLoader(ds, 2, shuffle=True, seed=1)
     sizes = [next(dl)[0].shape[0] for _ in range(6)]
     assert sizes == [2, 2, 1, 2, 2, 1]
+
+
+def test_unhomo_train_data_mixed_source_sizes(tmp_path):
+    """frames / masks of different sizes in one batch (per-item uploads instead of one stacked copy)"""
+    from dmhomo_amd.dataset import UnHomoTrainData
+    truth = _make_dataset(str(tmp_path), n=4, ragged=True)
+    ds = UnHomoTrainData(str(tmp_path), 96, device=dev())
+    got = ds.batch([0, 1, 2, 3])[0].cpu().numpy()
+    for i, name in enumerate(ds.im1_im2_names):
+        want = OD.build_item(*truth[name], 96)
+        assert np.abs(got[i, :6] - want[:6]).max() < 1e-6 and np.array_equal(got[i, 6], want[6]), name
 
 
 def test_trainer_trains_from_dataset_folder(tmp_path):

@@ -113,3 +113,18 @@ def test_record_files_split_into_the_hem_sample_format(tmp_path):
         r, i = divmod(k - 1, 3)
         assert buf['img12'].dtype == np.uint8 and np.array_equal(buf['img12'], recs[r]['imgs'][i])
         assert buf['homo12'].dtype == np.float64 and np.array_equal(buf['homo12'], recs[r]['homos'][i])
+
+
+def test_ema_decay_schedule():
+    """EMA stand-in: ema_pytorch's published warm-up — 0 until update_after_step, then
+    clamp(1 - (1 + epoch / inv_gamma) ** -power, min_value, beta) with epoch = step - update_after_step - 1"""
+    import torch
+    from dmhomo_amd.ddpm import EMA
+    e = EMA(torch.nn.Linear(2, 2), beta=0.995, update_every=10)
+    assert (e.update_after_step, e.inv_gamma, abs(e.power - 2 / 3) < 1e-12, e.min_value) == (100, 1.0, True, 0.0)
+    for step, want in ((0, 0.0), (100, 0.0), (101, 0.0), (102, 1 - 2 ** (-2 / 3)), (111, 1 - 11 ** (-2 / 3)),
+                       (100000, 0.995)):
+        e.step.fill_(step)
+        assert abs(e.get_current_decay() - want) < 1e-12, (step, e.get_current_decay(), want)
+    sd = e.state_dict()
+    assert {'initted', 'step', 'online_model.weight', 'ema_model.weight'} <= set(sd)
