@@ -1,4 +1,4 @@
-// Training, first pieces (in progress): backward of the LinearAttention core (CFG:258-269) on a
+// Training: backward of the LinearAttention core (CFG:258-269) on a
 // stored qkv tensor [B][n][384] (channel = part*128 + head*32 + d), as the unfused forward of attention.hip computes it:
 //   q' = softmax_d(q) * scale     k' = softmax_n(k)     ctx[d,e] = sum_n k'[d,n] v[e,n] / n     out[e,n] = sum_d ctx[d,e] q'[d,n]
 // Given dO = d out:

@@ -1,4 +1,4 @@
-// Training, first pieces (in progress): a strided, batched fp32 GEMM on v_mfma_f32_32x32x2_f32 for
+// Training: a strided, batched fp32 GEMM on v_mfma_f32_32x32x2_f32 for
 // the SMALL products of the backward pass (the bottleneck Attention's n x n maps at n = 256..1024, the embedding MLPs),
 // and row softmax forward / backward.  One wave per 32x32 output tile, operands read straight from global memory
 // (their lines stay in L1 across the K loop) — adequate for these sizes, not a general GEMM.

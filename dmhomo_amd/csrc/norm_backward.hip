@@ -1,4 +1,4 @@
-// Training, first pieces (in progress): backward of Block = GroupNorm -> (scale+1, shift) -> SiLU
+// Training: backward of Block = GroupNorm -> (scale+1, shift) -> SiLU
 // (CFG:196-213) given the conv output y it normalised, and of the weight standardisation (CFG:120-126).
 //
 // Forward (as dmh_gn_finalize folds it): z = a*y + c with a = rstd*gamma*(s+1), c = (beta - mean*rstd*gamma)*(s+1) + t,

@@ -1,4 +1,4 @@
-// Training, first pieces (in progress): the small kernels around the big ones.
+// Training: the small kernels around the big ones.
 //   act        SiLU / GELU(erf) forward and backward on the embedding MLPs (CFG:353,362,220)
 //   embedding  backward of classes_emb lookup + null-class select (CFG:419-425)
 //   loss       gradient of p_losses wrt the UNet output (CFG:796-806): L1 / L2 term + the alpha_bar-weighted, masked

@@ -219,7 +219,8 @@ int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, in
 int dmh_dlt_homography(const float* flow, double* ws, double* Hout, int B, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------------------------------
- * Training — first pieces, the rest of the backward pass is not built yet.
+ * Training: the pieces of loss.backward() / clip_grad_norm_ / Adam.step / ema.update (DDP:1843-1865);
+ * dmhomo_amd/train.py strings them into the optimiser step.
  * ------------------------------------------------------------------------------------- */
 
 /* weight / bias gradient of a stride-1 KHxKH convolution, i.e. autograd of F.conv2d (CFG:128) wrt weight and bias:
@@ -229,7 +230,9 @@ int dmh_dlt_homography(const float* flow, double* ws, double* Hout, int B, int H
  *                 input [B][H/2][W/2][C0] (Upsample, CFG:106-107);
  *   KH = 2      : 'valid' 2x2 conv (p = 0) over a stored input [B][H+1][W+1][C0] — the space-to-depth form
  *                 (dmh_s2d_shift) of the 4x4 / stride-2 Downsample conv (CFG:110-111).
- * Exact fp32 (v_mfma_f32_16x16x4_f32), deterministic (pixel splits reduced in a fixed order).  The DATA gradient is
+ * KH = 2, 3: fp16 pieces of both operands on the fp16 matrix cores, fp32 accumulate (error at the fp32-accumulation
+ * level; DMH_WGRAD_VARIANT=0: exact fp32 everywhere); KH = 1, 7: exact fp32 (v_mfma_f32_16x16x4_f32).  Deterministic
+ * (pixel splits reduced in a fixed order).  The DATA gradient is
  * dmh_conv2d itself on dy with the weight flipped in both taps and transposed in (Cout, Cin).
  * dy: NHWC [B][H][W][Cout]; dw: OIHW [Cout][C0+C1][KH][KH]; db: [Cout] or NULL; work: ..._workspace_floats floats. */
 int64_t dmh_conv_wgrad_workspace_floats(int B, int H, int W, int C0, int C1, int Cout, int KH);
