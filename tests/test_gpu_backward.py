@@ -449,3 +449,31 @@ def test_user_loop_loss_backward_and_torch_optimizer(golden_dir):
         torch.randint = orig
     print('[parity] user loop losses', losses)
     assert losses[2] < losses[1] < losses[0]
+
+
+def test_conv_wgrad_dynamic_range(ops):
+    """the fp16-piece weight-gradient kernel under the conditions its block scaling exists for: gradient magnitudes
+    from 1e-9 to 1e+3 and activations from 1e-4 to 1e+4 varying over decades ACROSS tiles (the running maxima rise and
+    fall along a workgroup's item range, the accumulators get rescaled), whole tiles of exact zeros (masked loss), and a
+    few isolated huge values — against fp64 autograd, error measured against the result's own scale"""
+    B, H, W, C, Co = 3, 32, 48, 64, 64
+    g = torch.Generator().manual_seed(910)
+    dy = torch.randn((B, Co, H, W), generator=g)
+    x = torch.randn((B, C, H, W), generator=g)
+    ramp = torch.logspace(-9, 3, W).view(1, 1, 1, W) * torch.logspace(0, -3, H).view(1, 1, H, 1)
+    dy = dy * ramp * torch.tensor([1.0, 1e-3, 1e2]).view(B, 1, 1, 1)
+    dy[:, :, 8:16, :] = 0.0                                         # zero tiles
+    dy[1, 5, 20, 7] = 3.0e3                                         # outliers
+    x = x * torch.logspace(4, -4, H).view(1, 1, H, 1)
+    x[2, 9, 3, 40] = -7.0e4
+    wd = torch.zeros((Co, C, 3, 3), dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(x.double(), wd, None, 1, 1)
+    gw, = torch.autograd.grad(y, wd, dy.double())
+    dw, db = ops.conv_wgrad(nhwc(dy), nhwc(x), None, k=3)
+    assert _rel('wgrad dynamic range dW', dw, gw) < 2e-6
+    assert _rel('wgrad dynamic range db', db, dy.double().sum((0, 2, 3))) < 2e-6
+    # per-tap check against each tap's own scale (a tap dominated by small-magnitude tiles must not drown)
+    for ky in range(3):
+        for kx in range(3):
+            r = ((dw[:, :, ky, kx].double().cpu() - gw[:, :, ky, kx]).abs().max() / gw[:, :, ky, kx].abs().max()).item()
+            assert r < 5e-6, (ky, kx, r)
