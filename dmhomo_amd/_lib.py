@@ -39,6 +39,8 @@ SIGNATURES = {
     'dmh_ws_standardize': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
     'dmh_conv_pack_floats': (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     'dmh_pack_conv_weight': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_conv_up2_pack_floats': (c_i64, [c_int, c_int]),
+    'dmh_pack_conv_weight_up2': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_conv_tiles': (c_int, [c_int, c_int, c_int, c_int]),
     'dmh_conv2d': (c_int, [C.POINTER(DmhConv), C.c_void_p]),
     'dmh_gn_finalize': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int,

@@ -384,6 +384,17 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   return DMH_OK;
 }
 
+// Upsample(nearest x2) + conv3x3 in its sub-pixel form (DmhConv.upsample2 == 2): -1 floats when this build / variant does
+// not offer it (the caller then packs with dmh_pack_conv_weight and upsample2 = 1)
+extern "C" int64_t dmh_conv_up2_pack_floats(int Cout, int C0) {
+  if (!use_f16x3(3, 1) || Cout % 64 != 0 || C0 % 4 != 0) return -1;
+  return dmh_f16x3_up2_pack_floats(Cout, C0);
+}
+extern "C" int dmh_pack_conv_weight_up2(const float* w, float* wpack, int Cout, int C0, void* stream) {
+  DMH_REQUIRE(w && wpack && dmh_conv_up2_pack_floats(Cout, C0) > 0, "dmh_pack_conv_weight_up2: bad arguments");
+  return dmh_f16x3_up2_pack(w, wpack, Cout, C0, (hipStream_t)stream);
+}
+
 extern "C" int dmh_ws_standardize(const float* w, float* w_out, int Cout, int K, float eps, void* stream) {
   DMH_REQUIRE(w && w_out && Cout > 0 && K > 0, "dmh_ws_standardize: bad arguments");
   hipLaunchKernelGGL(ws_standardize_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, w_out, K, eps);
@@ -430,6 +441,10 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 9: return dmh_f16x3_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
+    case 312:  // Upsample + 3x3 with a weight packed by dmh_pack_conv_weight_up2: four 2x2 sub-pixel convs
+      DMH_REQUIRE(use_f16x3(3, 1) && !d->src1 && d->Cout % 64 == 0 && !d->stats,
+                  "dmh_conv2d: the sub-pixel upsampling conv needs the fp16-piece kernels, one source, Cout %% 64 == 0, no stats");
+      return dmh_f16x3_launch_up2(d, Hout, Wout, st);
     case 710:
       if (use_f16x3(7, 1)) return dmh_f16x3_launch(d, Hout, Wout, st);
       return launch_conv<7, 7, 1, 0, 16, 16, 16>(d, Hout, Wout, st);

@@ -70,6 +70,9 @@ int dmh_bf16x3_launch3(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 int64_t dmh_f16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW);
 int dmh_f16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st);
 int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
+int64_t dmh_f16x3_up2_pack_floats(int Cout, int C0);
+int dmh_f16x3_up2_pack(const float* w, float* wpack, int Cout, int C0, hipStream_t st);
+int dmh_f16x3_launch_up2(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 
 // Winograd on the bf16 matrix cores, fp32 carried as three bf16 pieces (conv_wino_bf16x3.hip)
 int64_t dmh_winobx_pack_floats(int Cout, int C0, int C1);
@@ -107,20 +110,24 @@ struct EpilogueRows {
   }
 
   // wl: this wave's 32 slab rows; row_base: tile-row index of slab row 0 (row -> pixel (row / TW, row % TW))
+  // (mul, dy, dx): the tile's pixel (y, x) lands on output pixel (mul*y + dy, mul*x + dx) — (2, parity) for the sub-pixel
+  // form of Upsample + conv3x3, whose tiles live on the low-resolution grid
   template <int TW>
-  __device__ __forceinline__ void store_rows(const ConvArgs& p, const float* wl, int row_base, int oy0, int ox0) {
+  __device__ __forceinline__ void store_rows(const ConvArgs& p, const float* wl, int row_base, int oy0, int ox0,
+                                             int mul = 1, int dy = 0, int dx = 0) {
     const int c4_ = c4;
-    store_rows_fn<TW>(p, [wl, c4_](int rr) { return ld4(wl + rr * EP + c4_ * 4); }, row_base, oy0, ox0);
+    store_rows_fn<TW>(p, [wl, c4_](int rr) { return ld4(wl + rr * EP + c4_ * 4); }, row_base, oy0, ox0, mul, dy, dx);
   }
 
   // same, the 32 rows x this lane's channel quad coming from fetch(rr) instead of a plain slab
   template <int TW, typename Fetch>
-  __device__ __forceinline__ void store_rows_fn(const ConvArgs& p, Fetch fetch, int row_base, int oy0, int ox0) {
+  __device__ __forceinline__ void store_rows_fn(const ConvArgs& p, Fetch fetch, int row_base, int oy0, int ox0,
+                                                int mul = 1, int dy = 0, int dx = 0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rr = i * 4 + rsub;
       const int row = row_base + rr;
-      const int oy = oy0 + row / TW, ox = ox0 + row % TW;
+      const int oy = (oy0 + row / TW) * mul + dy, ox = (ox0 + row % TW) * mul + dx;
       if (cok && oy < p.Hout && ox < p.Wout) {
         float4 val = fetch(rr);
         const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;

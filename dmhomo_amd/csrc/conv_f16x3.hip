@@ -56,9 +56,16 @@ constexpr int STEP_U4 = 4 * 64;       // uint4 per (chunk, tap, cout half): 2 co
 template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
 struct F16Cfg {
   static_assert(WM * WN == 4, "four waves per workgroup");
-  static_assert(TH * TW == WM * 64, "64 pixels per wave");
-  static constexpr int IN_H = (TH - 1) * S + KH;
-  static constexpr int IN_W = (TW - 1) * S + KW;
+  // UPS == 3: the sub-pixel form of Upsample(nearest x2) + conv3x3.  Output pixel (2y+dy, 2x+dx) only sees the 2x2
+  // low-resolution pixels (y+dy-1 .. y+dy, x+dx-1 .. x+dx), through weights that are sums of the 3x3 taps falling on the
+  // same source pixel: four 2x2 convs (one per parity) instead of one 3x3 at the high resolution, 16 instead of 36
+  // multiply-adds per low-resolution pixel.  The tile is 4 x 16 LOW-resolution pixels; wave w owns parity (w >> 1, w & 1)
+  // of all 64 of them, with its own weight stream (the packed weight holds 4*Cout virtual output channels).
+  static constexpr bool SUB = UPS == 3;
+  static_assert(SUB || TH * TW == WM * 64, "64 pixels per wave");
+  static_assert(!SUB || (KH == 2 && KW == 2 && S == 1 && TH == 4 && TW == 16 && WM == 4 && WN == 1), "sub-pixel geometry");
+  static constexpr int IN_H = SUB ? TH + 2 : (TH - 1) * S + KH;
+  static constexpr int IN_W = SUB ? TW + 2 : (TW - 1) * S + KW;
   static constexpr int IN_PIX = IN_H * IN_W;
   static constexpr int NLOAD = (IN_PIX * 8 + 255) / 256;
   static constexpr int PAD = UPS == 2 ? 0 : ((S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0));  // UPS == 2: cell (oy, ox) is tap (0,0)
@@ -107,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   t /= p.tilesX;
   const int ty = t % p.tilesY;
   const int b = t / p.tilesY;
-  const int nt = by * WN + wn;
-  const int n0 = nt * 64;
+  const int nt = UPS == 3 ? wm * (int)gridDim.y + by : by * WN + wn;  // UPS == 3: virtual channels [parity][cout tile]
+  const int n0 = UPS == 3 ? by * 64 : nt * 64;                          // output channels of this wave
 
   const int oy0 = ty * TH, ox0 = tx * TW;
   const int iy0 = oy0 * S - Cfg::PAD, ix0 = ox0 * S - Cfg::PAD;
@@ -137,7 +144,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   static_assert(TW == 16, "a 16-row MFMA block is one tile row");
   int arow[4];
 #pragma unroll
-  for (int mb = 0; mb < 4; ++mb) arow[mb] = ((wm * 4 + mb) * S) * ROWP + (l15 * S) * PITCH + kg * 16;
+  for (int mb = 0; mb < 4; ++mb)
+    arow[mb] = UPS == 3 ? (mb + (wm >> 1)) * ROWP + (l15 + (wm & 1)) * PITCH + kg * 16
+                        : ((wm * 4 + mb) * S) * ROWP + (l15 * S) * PITCH + kg * 16;
 
   // accumulators: 4 row blocks x 4 column blocks of 16x16 (C/D layout: row = 4 * (lane >> 4) + r, col = lane & 15)
   float4v acc[4][4];
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     const float inv_s = __uint_as_float((unsigned)(e_run - 14) << 23);  // 1 / sc
     float* wl = lds + wave * (32 * EP);
     EpilogueRows er(p, b, n0);
+    if (UPS == 3 && p.oscale) er.osc = ld4(p.oscale + nt * 64 + er.c4 * 4);  // the weight scale of the VIRTUAL channel
 #pragma unroll
     for (int hb = 0; hb < 2; ++hb) {  // two passes of 32 pixel rows through the wave's slab
       __syncthreads();
@@ -345,7 +355,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
           for (int r = 0; r < 4; ++r)
             wl[(m2 * 16 + kg * 4 + r) * EP + nb * 16 + l15] = acc[hb * 2 + m2][nb][r] * inv_s;
       __syncthreads();
-      er.template store_rows<TW>(p, wl, wm * 64 + hb * 32, oy0, ox0);
+      if (UPS == 3) er.template store_rows<TW>(p, wl, hb * 32, oy0, ox0, 2, wm >> 1, wm & 1);
+      else er.template store_rows<TW>(p, wl, wm * 64 + hb * 32, oy0, ox0);
     }
 #ifdef DMH_STAMPS
     STAMP(5)  // epilogue
@@ -477,6 +488,59 @@ static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
   dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64 * WN));
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, a);
   DMH_CHECK_LAUNCH("dmh_conv2d(f16x3)");
+  return DMH_OK;
+}
+
+// ---- sub-pixel form of Upsample + conv3x3 (UPS == 3)
+// wv[(par*Cout + o)][c][a][b] = sum of w[o][c][ky][kx] over the taps that fall on low-resolution source pixel (a, b) of
+// parity par = (dy, dx):  dy = 0: a = 0 <- ky 0, a = 1 <- ky 1, 2;   dy = 1: a = 0 <- ky 0, 1, a = 1 <- ky 2  (same in x)
+__global__ void subpixel_weight_kernel(const float* __restrict__ w, float* __restrict__ wv, int Cout, int Cin) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)4 * Cout * Cin * 4;
+  if (idx >= total) return;
+  const int tb = idx & 1, ta = (idx >> 1) & 1;
+  int64_t r = idx >> 2;
+  const int c = r % Cin;
+  r /= Cin;
+  const int o = r % Cout, par = r / Cout;
+  const int dy = par >> 1, dx = par & 1;
+  const int ky0 = dy == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), ky1 = dy == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+  const int kx0 = dx == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), kx1 = dx == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+  const float* wk = w + ((size_t)o * Cin + c) * 9;
+  float s = 0.f;
+  for (int ky = ky0; ky <= ky1; ++ky)
+    for (int kx = kx0; kx <= kx1; ++kx) s += wk[ky * 3 + kx];
+  wv[idx] = s;
+}
+
+int64_t dmh_f16x3_up2_pack_floats(int Cout, int C0) {
+  return dmh_f16x3_pack_floats(4 * Cout, C0, 0, 2, 2) + (int64_t)16 * Cout * C0;  // + the summed weights (pack-time scratch)
+}
+
+int dmh_f16x3_up2_pack(const float* w, float* wpack, int Cout, int C0, hipStream_t st) {
+  float* wv = wpack + dmh_f16x3_pack_floats(4 * Cout, C0, 0, 2, 2);
+  const int64_t total = (int64_t)16 * Cout * C0;
+  hipLaunchKernelGGL(subpixel_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, w, wv, Cout, C0);
+  return dmh_f16x3_pack(wv, wpack, 4 * Cout, C0, 0, 2, 2, st);
+}
+
+int dmh_f16x3_launch_up2(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
+  using Cfg = F16Cfg<2, 2, 1, 3, 4, 16, 4, 1>;
+  ConvArgs a = fill_conv_args(d, Hout, Wout, KC, 4, 16);
+  a.tilesX = cdiv(d->Win, 16);  // tiles live on the low-resolution grid
+  a.tilesY = cdiv(d->Hin, 4);
+  a.oscale = d->wpack + f16x3_frag_floats(4 * d->Cout, a.C0, 0, 2, 2);
+  auto kern = conv_f16x3_kernel<2, 2, 1, 3, 4, 16, 4, 1>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       Cfg::LDS_BYTES);
+    DMH_REQUIRE(e == hipSuccess, "dmh_conv2d: cannot raise the LDS limit: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64));
+  hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, a);
+  DMH_CHECK_LAUNCH("dmh_conv2d(f16x3 sub-pixel)");
   return DMH_OK;
 }
 

@@ -12,6 +12,8 @@ from . import _lib
 from ._lib import call, ptr, lib
 
 F32 = torch.float32
+# DMH_UP_SUBPIXEL=0: keep Upsample + conv3x3 as one 3x3 conv over the (virtually) upsampled input
+SUBPIXEL_UP = __import__('os').environ.get('DMH_UP_SUBPIXEL', '1') != '0'
 
 
 def _empty(shape, like, dtype=F32):
@@ -32,13 +34,19 @@ class PackedConv:
     """a conv weight in dmh_conv2d's tile-major layout + its geometry."""
     __slots__ = ('wpack', 'bias', 'cout', 'c0', 'c1', 'k', 'stride', 'upsample2')
 
-    def __init__(self, w_oihw, bias, c0, c1=0, stride=1, upsample2=0):
+    def __init__(self, w_oihw, bias, c0, c1=0, stride=1, upsample2=0, subpixel=True):
         w = w_oihw.detach().contiguous()
         cout, cin, kh, kw = w.shape
         assert cin == c0 + c1 and kh == kw, (w.shape, c0, c1)
-        n = lib().dmh_conv_pack_floats(cout, c0, c1, kh, kw)
-        self.wpack = _empty((n,), w)
-        call('dmh_pack_conv_weight', ptr(w), ptr(self.wpack), cout, c0, c1, kh, kw)
+        n_up2 = lib().dmh_conv_up2_pack_floats(cout, c0) if (upsample2 and kh == 3 and c1 == 0 and subpixel and SUBPIXEL_UP) else -1
+        if n_up2 > 0:                     # Upsample + conv3x3 as four 2x2 sub-pixel convs (upsample2 = 2)
+            self.wpack = _empty((n_up2,), w)
+            call('dmh_pack_conv_weight_up2', ptr(w), ptr(self.wpack), cout, c0)
+            upsample2 = 2
+        else:
+            n = lib().dmh_conv_pack_floats(cout, c0, c1, kh, kw)
+            self.wpack = _empty((n,), w)
+            call('dmh_pack_conv_weight', ptr(w), ptr(self.wpack), cout, c0, c1, kh, kw)
         self.bias = None if bias is None else bias.detach().contiguous()
         self.cout, self.c0, self.c1, self.k, self.stride, self.upsample2 = cout, c0, c1, kh, stride, upsample2
 

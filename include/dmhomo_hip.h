@@ -56,6 +56,13 @@ int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW);
  * straddle the two concatenated sources; padding is zero. */
 int dmh_pack_conv_weight(const float* w_oihw, float* wpack, int Cout, int C0, int C1, int KH, int KW,
                          void* stream);
+/* Upsample(nearest x2) + conv3x3 (CFG:106-107) in its sub-pixel form: output pixel (2y+dy, 2x+dx) depends on a 2x2
+ * low-resolution neighbourhood through sums of the 3x3 taps, so the conv runs as four 2x2 convs (16 instead of 36
+ * multiply-adds per low-resolution pixel; tap sums are formed in fp32 at pack time).  dmh_conv_up2_pack_floats returns
+ * -1 when the build's conv variant / the shape (Cout % 64, one source) does not offer it; use the image with
+ * DmhConv.upsample2 = 2, KH = KW = 3, stride = 1. */
+int64_t dmh_conv_up2_pack_floats(int Cout, int C0);
+int dmh_pack_conv_weight_up2(const float* w_oihw, float* wpack, int Cout, int C0, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K1/K2  convolution as an implicit GEMM.  fp32 tensors in and out; by default the products run on the fp16
@@ -81,7 +88,8 @@ typedef struct DmhConv {
   int32_t B, Hin, Win, C0, C1, Cout;
   int32_t KH, KW;     /* 1x1, 3x3, 7x7 (stride 1, pad k/2); 4x4 (stride 2, pad 1); 2x2 (stride 2, pad 0) */
   int32_t stride;     /* 1 or 2 */
-  int32_t upsample2;  /* 1: nearest x2 of the input fused into the 3x3 gather (Upsample, CFG:106-107) */
+  int32_t upsample2;  /* 1: nearest x2 of the input fused into the 3x3 gather (Upsample, CFG:106-107);
+                         2: the same conv with a wpack from dmh_pack_conv_weight_up2 (four 2x2 sub-pixel convs) */
 } DmhConv;
 
 /* tiles per sample that dmh_conv2d will use for this geometry (size of the stats buffer) */

@@ -44,6 +44,8 @@ CONV_CASES = [
     ('4x4s2 128->256 16x16', 2, 16, 16, 128, 0, 256, 4, 2, 0),
     ('3x3 tiny 4x4 256->512', 2, 4, 4, 256, 0, 512, 3, 1, 0),
     ('3x3 upsample wide 128->128 12x20', 2, 12, 20, 128, 0, 128, 3, 1, 1),
+    ('3x3 upsample sub-pixel 128->64 9x21 (ragged low-res tiles)', 2, 9, 21, 128, 0, 64, 3, 1, 1),
+    ('3x3 upsample sub-pixel 512->256 16x16', 2, 16, 16, 512, 0, 256, 3, 1, 1),
     ('3x3 concat wide 128+64->128 17x9', 1, 17, 9, 128, 64, 128, 3, 1, 0),
     ('3x3 odd channels 36->20 11x13', 2, 11, 13, 36, 0, 20, 3, 1, 0),
     ('3x3 512->512 2x2 (image smaller than a tile, 16 chunks)', 3, 2, 2, 512, 0, 512, 3, 1, 0),
@@ -68,8 +70,15 @@ def test_conv2d(ops, case):
     pc = ops.PackedConv(w.to(dev()), b.to(dev()), C0, C1, stride, ups)
     s0 = nhwc(x[:, :C0])
     s1 = nhwc(x[:, C0:]) if C1 else None
-    out, stats = ops.conv2d(pc, s0, s1, want_stats=True)
     ref = ref_conv(x, w, b, k, stride, ups)
+    if pc.upsample2 == 2:
+        # Upsample + conv3x3 packed in its sub-pixel form (four 2x2 convs, no GroupNorm partials): checked on its own,
+        # then the classic form (one 3x3 over the virtually upsampled input) goes through the common checks below
+        close(name + ' [sub-pixel]', nchw(ops.conv2d(pc, s0, s1)), ref, rtol=1e-4, atol=2e-5)
+        with pytest.raises(ops._lib.DmhError):
+            ops.conv2d(pc, s0, s1, want_stats=True)
+        pc = ops.PackedConv(w.to(dev()), b.to(dev()), C0, C1, stride, ups, subpixel=False)
+    out, stats = ops.conv2d(pc, s0, s1, want_stats=True)
     close(name, nchw(out), ref, rtol=1e-4, atol=2e-5)
     # per-tile GroupNorm partials sum to the per-channel totals
     tot = stats.sum(dim=1).cpu().double()

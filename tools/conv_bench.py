@@ -54,12 +54,12 @@ def main():
         if pro:
             coef = torch.stack([1 + 0.1 * torch.randn(B, C0, device=dev), 0.1 * torch.randn(B, C0, device=dev)], 1).contiguous()
         for _ in range(3):
-            out = ops.conv2d(pc, s0, s1, in_coef=coef, want_stats=(k == 3))
+            out = ops.conv2d(pc, s0, s1, in_coef=coef, want_stats=(k == 3 and pc.upsample2 != 2))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(args.reps):
-            out = ops.conv2d(pc, s0, s1, in_coef=coef, want_stats=(k == 3))
+            out = ops.conv2d(pc, s0, s1, in_coef=coef, want_stats=(k == 3 and pc.upsample2 != 2))
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / args.reps * 1e3
