@@ -60,7 +60,7 @@ def conv_out_hw(pc, h, w):
 
 
 # launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline leg):
-# when a list, every dmh_conv2d launch appends (start_event, end_event, k, stride, B, Hout, Wout, Cin, Cout)
+# when a list, every dmh_conv2d launch appends (start_event, end_event, k, stride, B, Hout, Wout, Cin, Cout, upsample2)
 CONV_LOG = None
 
 
@@ -85,7 +85,7 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
         e0.record()
         call('dmh_conv2d', C.byref(d))
         e1.record()
-        CONV_LOG.append((e0, e1, pc.k, pc.stride, B, ho, wo, pc.c0 + pc.c1, pc.cout))
+        CONV_LOG.append((e0, e1, pc.k, pc.stride, B, ho, wo, pc.c0 + pc.c1, pc.cout, pc.upsample2))
     else:
         call('dmh_conv2d', C.byref(d))
     return (out, stats) if want_stats else out
