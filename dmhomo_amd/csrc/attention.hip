@@ -76,8 +76,10 @@ __global__ __launch_bounds__(1024) void linattn_merge_kernel(const float* __rest
   const float* base = partial + ((size_t)b * nsplit * 4 + h) * LA_PART;
   const size_t stride = (size_t)4 * LA_PART;
   float M = -INFINITY;
+#pragma unroll 8  // the loads of 8 splits in flight (the chain itself is short; the latency of a dependent load per split was not)
   for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, base[sp * stride + d]);
   float S = 0.f, acc = 0.f;
+#pragma unroll 8
   for (int sp = 0; sp < nsplit; ++sp) {
     const float w = expf(base[sp * stride + d] - M);
     S = fmaf(base[sp * stride + 32 + d], w, S);
