@@ -208,6 +208,43 @@ def test_upsample_conv_backward(ops, C, Co, H, W):
     assert _rel('up db', db, gb) < 3e-6
 
 
+def test_unet_backward_full_width_ragged_vs_autograd():
+    """the same at the DGM width (dim 64: 64..512 channels, every fp16-piece weight-gradient / data-gradient shape of the
+    real model, the sub-pixel upsampling convs in the training forward) on a 24x24 image (ragged tiles at every level)"""
+    from test_gpu_unet import make_cfg, _cond_inputs, g
+    from dmhomo_amd import train
+    from oracle import unet as OU
+    m, sd = make_cfg(64)
+    B, S = 2, 24
+    x, rf, mk = _cond_inputs(B, S, 710)
+    t = torch.tensor([17, 803])
+    c = torch.zeros(B, dtype=torch.long)
+    keep = torch.tensor([True, False])
+    dout = rand((B, 6, S, S), 711)
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    out_ref = OU.cfg_unet_forward(sdd, x, t, c, rf, mk, keep)
+    pnames = [k for k, _ in m.named_parameters()]
+    ref = dict(zip(pnames, torch.autograd.grad(out_ref, [sdd[k] for k in pnames], dout, allow_unused=True)))
+    ut = train.UnetTrain(m)
+    out, saved = ut.forward(g(x), g(t), g(c), g(rf), g(mk), g(keep))
+    assert _rel('unet64 train fwd', out, out_ref.detach()) < 2e-4
+    got = ut.backward(saved, g(dout))
+    worst = 0.0
+    for k in pnames:
+        if ref[k] is None:
+            continue
+        if ref[k].abs().max() < 1e-4:
+            assert got[k].abs().max().item() < 1e-3, k
+            continue
+        r = ((got[k].double().cpu().reshape(ref[k].shape) - ref[k].double()).abs().max() /
+             ref[k].double().abs().max().clamp_min(1e-30)).item()
+        if r > 1e-4:
+            print(f'[parity] unet64 bwd {k}: rel_to_max={r:.3e}')
+        worst = max(worst, r)
+    print(f'[parity] unet64 bwd (24x24): {len(pnames)} parameter gradients, worst rel_to_max={worst:.3e}')
+    assert worst < 2e-3, worst
+
+
 def test_unet_backward_vs_autograd():
     """the whole conditional UNet (CFG:412-466), tiny geometry: forward with saved activations + backward on the HIP
     kernels against torch autograd through the oracle's functional forward in fp64 — every parameter's gradient"""

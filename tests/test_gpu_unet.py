@@ -110,6 +110,25 @@ def test_unet_cfg_fullsize_vs_oracle():
     close('cfg full out', out.cpu(), ref, rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize('size,B', [(40, 3), (72, 1)])
+def test_unet_cfg_ragged_sizes_vs_oracle(size, B):
+    """image sizes that are multiples of 8 but not of the kernels' tiles (40: 16-pixel tiles end ragged at every level,
+    the 5x5 bottleneck attention has 25 keys, the sub-pixel upsampling convs see 5 / 10 / 20-pixel rows; 72: 9x9
+    bottleneck), dim = 64 so that every fused / fp16-piece path is taken; single sample too"""
+    m, sd = make_cfg(64)
+    x, rf, mk = _cond_inputs(B, size, 300 + size)
+    t = torch.tensor([967, 30, 400][:B])
+    c = torch.zeros(B, dtype=torch.long)
+    keep = torch.tensor([True, False, True][:B])
+    rtaps, taps = {}, {}
+    with torch.no_grad():
+        ref = OU.cfg_unet_forward(sd, x, t, c, rf, mk, keep, taps=rtaps)
+    out = m._run(g(x), g(t), g(c), g(rf), g(mk), [g(keep.to(torch.uint8))], taps=taps)
+    worst = max(report(f'ragged{size} ' + k, nchw(taps[k]), rtaps[k])[1] for k in rtaps)
+    assert worst < 1e-3, worst
+    close(f'cfg ragged {size} out', out.cpu(), ref, rtol=1e-3, atol=2e-4)
+
+
 def test_unet_rows_are_independent():
     """size-independent property: each output row depends on its own sample only (bitwise) — what makes
     sample-sharding across GPUs exact"""
