@@ -31,8 +31,8 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // x * sigmoid(x) written as torch's CPU SiLU does it: x / (1 + exp(-x))
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
-// same function on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1-2 ulp): used where the
-// SiLU sits in a conv prologue and its VALU cost competes with the matrix pipe
+// same function on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1-2 ulp): used on the sampling / forward
+// path — conv prologues, the residual epilogue and gn_silu_residual — where its VALU cost is visible (+0.8 % images/s)
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -138,10 +138,10 @@ struct EpilogueRows {
         if (p.res) {
           const float4 rv = ld4(p.res + o);
           if (p.res_coef) {
-            val.x += silu_f(fmaf(ra.x, rv.x, rb.x));
-            val.y += silu_f(fmaf(ra.y, rv.y, rb.y));
-            val.z += silu_f(fmaf(ra.z, rv.z, rb.z));
-            val.w += silu_f(fmaf(ra.w, rv.w, rb.w));
+            val.x += silu_fast(fmaf(ra.x, rv.x, rb.x));
+            val.y += silu_fast(fmaf(ra.y, rv.y, rb.y));
+            val.z += silu_fast(fmaf(ra.z, rv.z, rb.z));
+            val.w += silu_fast(fmaf(ra.w, rv.w, rb.w));
           } else {
             val.x += rv.x;
             val.y += rv.y;

@@ -66,10 +66,10 @@ __global__ __launch_bounds__(256) void gn_silu_residual_kernel(const float* __re
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (res) r = ld4(res + i * 4);
     float4 o;
-    o.x = silu_f(fmaf(a.x, v.x, bb.x)) + r.x;
-    o.y = silu_f(fmaf(a.y, v.y, bb.y)) + r.y;
-    o.z = silu_f(fmaf(a.z, v.z, bb.z)) + r.z;
-    o.w = silu_f(fmaf(a.w, v.w, bb.w)) + r.w;
+    o.x = silu_fast(fmaf(a.x, v.x, bb.x)) + r.x;
+    o.y = silu_fast(fmaf(a.y, v.y, bb.y)) + r.y;
+    o.z = silu_fast(fmaf(a.z, v.z, bb.z)) + r.z;
+    o.w = silu_fast(fmaf(a.w, v.w, bb.w)) + r.w;
     st4(out + i * 4, o);
   }
 }
