@@ -14,40 +14,80 @@ weights are seeded random init (the trained DGM.pt is not available offline; spe
 independent), noise comes from the device Philox generator.  Samples shard across ranks with no
 data-path collective -> "scaling": "weak" (25 samples per GPU).
 
+N > 1 without a torchrun environment: this process only LAUNCHES (it never touches the GPU): it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line and exits
+with the child's code — the counterpart of the reference's N hand-started processes (README:14,
+DGM/dgm_sample.py:13-18).
+
 Prints ONE JSON line on rank 0, including
-  roofline     the dominant kernel (3x3 conv, conv_f16x3_kernel: implicit GEMM on the fp16 matrix cores, every
-               fp32 product carried by three fp16 MFMAs under block scaling): ALGORITHMIC FLOPs
-               (2*9*Cin*Cout*H*W*B) of its launches / their HIP-event durations, vs the
-               157.3 TFLOP/s dense fp32 MFMA peak of MI355X (MI355X_MICROARCH.md; the dtype the path
-               computes in is f32).  The kernel does not use the fp32 MFMA, so `frac` can exceed 1;
-               `executed` is the same time priced on the pipe that actually runs: 3 fp16 MFMA FLOPs per
-               algorithmic FLOP vs the 2.5 PFLOP/s dense fp16 peak.  With
-               --cfg-mode streams (default) the two CFG passes run on two HIP streams and their kernels
-               overlap, so per-launch durations are not exclusive: the roofline leg is then measured on
-               one extra, untimed step in batched mode (same kernels, same shapes, 2B rows per launch)
+  roofline     the dominant kernel (stride-1 3x3 conv, conv_f16x3_kernel<3,3,1,0,...>: implicit GEMM on the fp16
+               matrix cores, every fp32 product carried by three fp16 MFMAs under block scaling).
+               achieved = ALGORITHMIC FLOPs (2*9*Cin*Cout*H*W*B) of its launches / their HIP-event
+               durations;  peak = the dense fp16 MFMA peak of MI355X (2.5 PFLOP/s, MI355X_MICROARCH.md) / 3 executed
+               FLOPs per algorithmic FLOP = 833 algorithmic TFLOP/s: the ceiling of this arithmetic on the pipe it
+               runs on;  frac = achieved / peak (= executed fp16-MFMA FLOP/s / 2.5 PFLOP/s).  Beside it
+               `hbm_frac_canonical`: the north_star's yardstick, algorithmic bytes of the canonical fused
+               conv3x3+GN+SiLU 64->64 @128^2 launch / its time / 8 TB/s (target >= 0.30), and `vs_fp32_mfma_peak`
+               (what an exact-fp32 MFMA kernel could reach at most).  HIP events sit on the launch stream around
+               every dmh_conv2d of ONE EXTRA untimed step in batched mode (exclusive per-launch durations: in the
+               default 'streams' mode the two CFG passes overlap); the timed region itself carries no events.
+               traffic = HBM bytes per launch of that kernel from the rocprofv3 PMC passes committed under
+               profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate passes) — not measured by this process, and tagged
+               with its source file
   cpu_baseline the oracle (a port of the reference's CPU path, bit-equal to it on the build host)
                timed on this box's host cores on a bounded sample (bs=2, s_step=4, same network).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3
-PEAK_FP16_MFMA_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (same guide); the executed pipe of conv_f16x3_kernel
+PEAK_FP32_MFMA_TFLOPS = 157.3     # dense fp32 MFMA = fp32 vector peak (MI355X_MICROARCH.md)
+PEAK_FP16_MFMA_TFLOPS = 2500.0    # dense fp16 / bf16 MFMA peak (same guide); the pipe conv_f16x3_kernel executes on
+PEAK_HBM_TBS = 8.0                # HBM3E peak (same guide)
+F16X3_TERMS = 3                   # executed fp16 MFMA FLOPs per algorithmic FLOP (h2*g1s + h1*g2 + h1*g1)
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as a child process tree and relay
+    rank 0's JSON line.  This parent makes no HIP / torch.cuda call (it does not even import torch) and never
+    re-execs itself; it exits non-zero when any rank failed."""
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault('OMP_NUM_THREADS', '8')
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.startswith('{') and '"metric"' in out:
+            line = out.strip()
+        else:
+            sys.stdout.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc != 0 or line is None:
+        print(f'bench.py: the {n}-rank child run failed (exit code {rc}, JSON line {"present" if line else "missing"})',
+              file=sys.stderr)
+        sys.exit(rc if rc != 0 else 1)
 
 
 def cpu_baseline(dim, image_size, seconds=12.0):
     """oracle (kind 'port') on the host cores: bs=2, s_step=4 passes of the same network, reported as
     images/s at s_step=32 (cost per denoise step is constant, so x 4/32)."""
+    import torch
     from oracle import diffusion as OD
     from detweights import det_state_dict, shapes_of
     from dmhomo_amd import cfg
@@ -85,6 +125,50 @@ def cpu_baseline(dim, image_size, seconds=12.0):
                       f'images/s scaled by 4/32 to s_step=32'}
 
 
+def plumbing_only(args):
+    """tests/test_distributed_cpu.py only: the N > 1 plumbing of this script (launcher -> ranks -> process group ->
+    weight payload -> shards -> gather -> max-over-ranks timing -> ONE JSON line) on gloo / CPU, with the sampling
+    step left out — there is no CPU path for it.  Refuses to run outside that test."""
+    if os.environ.get('DMH_BENCH_PLUMBING_TEST') != '1':
+        raise RuntimeError('bench.py --device cpu is a test-only plumbing mode (tests/test_distributed_cpu.py); the '
+                           'benchmark itself needs MI355X GPUs — there is no CPU path')
+    import torch
+    import torch.distributed as dist
+    from dmhomo_amd import cfg
+    from dmhomo_amd import distributed as D
+    rank, world, device = D.init_from_env('gloo')
+    assert world == args.gpus and device.type == 'cpu'
+    torch.manual_seed(rank)                               # different weights per rank before the payload
+    model = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1)
+    diffusion = cfg.GaussianDiffusion(model, image_size=16, timesteps=50, sampling_timesteps=4, objective='pred_x0')
+    D.broadcast_module_(diffusion, src=0)
+    digest = torch.tensor([float(sum(p.double().sum() for p in diffusion.state_dict().values()))], dtype=torch.float64)
+    lo, hi = D.shard_bounds(args.bs * world, rank, world)
+    imgs = torch.arange(lo, hi, dtype=torch.uint8).reshape(-1, 1, 1, 1).expand(-1, 6, 4, 4).contiguous()
+    homos = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1, 1).expand(-1, 3, 3).contiguous()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gi, gh = D.gather_records(imgs, homos, dst=0)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ranks = torch.ones(1)
+    dist.all_reduce(ranks)
+    dmin, dmax = digest.clone(), digest.clone()
+    dist.all_reduce(dmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(dmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        ok = (gi[:, 0, 0, 0].tolist() == list(range(args.bs * world)) and gh[:, 0, 0].tolist() ==
+              [float(i) for i in range(args.bs * world)] and float(dmin) == float(dmax))
+        print(json.dumps({'metric': 'plumbing only (no sampling: CPU test mode)', 'value': None, 'n_gpus': world,
+                          'steps': args.steps, 'warmup': args.warmup, 'rccl_ranks': int(ranks.item()),
+                          'backend': dist.get_backend(), 'plumbing_only': True, 'records_in_rank_order': bool(ok),
+                          'global_batch': args.bs * world, 'elapsed_s': float(t.item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -97,13 +181,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cfg-mode', default='streams', choices=['batched', 'streams'])
     ap.add_argument('--stream-splits', type=int, default=1, help="row sub-batches per CFG pass in 'streams' mode")
-    ap.add_argument('--no-conv-events', action='store_true', help='skip the per-launch HIP events')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the extra untimed step that carries the HIP events')
     ap.add_argument('--variants', action='store_true',
                     help='also time the opt-in dedup_dropped_rows mode (3 extra steps) and report it under "variants"')
     ap.add_argument('--workload', default='sample', choices=['sample', 'train'],
                     help="'train': the optimiser step of BASELINE configs[3] (16 images per GPU, gradients averaged over "
                          "RCCL) instead of the headline sampling loop; same launch contract, see tools/train_bench.py")
+    ap.add_argument('--device', default='cuda', choices=['cuda', 'cpu'],
+                    help="'cpu' is the test-only plumbing mode of tests/test_distributed_cpu.py (raises elsewhere)")
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args.gpus, sys.argv[1:])       # before anything touches torch / the GPU
+    if args.device == 'cpu':
+        return plumbing_only(args)
     if args.workload == 'train':
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         import train_bench
@@ -114,12 +204,13 @@ def main():
             print(json.dumps(line))
         return
 
+    import torch
     import torch.distributed as dist
     from dmhomo_amd import cfg, ddpm, ops
     from dmhomo_amd import distributed as D
 
     rank, world, device = D.init_from_env()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
     assert device.type == 'cuda', 'bench.py needs MI355X GPUs (no CPU path)'
 
     # ---- model: seeded init on every rank, then rank 0's weights win (one scatter+all-gather payload)
@@ -152,25 +243,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ops.CONV_LOG = None if args.no_conv_events else []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    log, ops.CONV_LOG = ops.CONV_LOG, None
-    roofline_mode = args.cfg_mode
-    if log is not None and args.cfg_mode == 'streams':
-        # exclusive per-launch durations: one extra untimed step with the cond+null rows in ONE launch sequence
+    # ---- roofline leg: HIP events on the launch stream around every dmh_conv2d of ONE EXTRA untimed step with the
+    # cond + null rows in one launch sequence (exclusive per-launch durations; same kernels, same shapes)
+    log = None
+    if not args.no_roofline and rank == 0:
         model.cfg_mode = 'batched'
-        step()
-        fence()
+        step_local = lambda: diffusion.sample(classes, rgb_flow, flow, mask)   # no collective: rank 0 only
+        step_local()
+        torch.cuda.synchronize()
         ops.CONV_LOG = []
-        step()
-        fence()
+        step_local()
+        torch.cuda.synchronize()
         log, ops.CONV_LOG = ops.CONV_LOG, None
         model.cfg_mode = args.cfg_mode
-        roofline_mode = 'batched (extra untimed step)'
     # ---- --variants: reported beside the headline, never as it: the opt-in de-duplication of the conditional pass's
     # dropped rows (cfg.Unet.dedup_dropped_rows: identical outputs, B + kept rows per denoise step instead of 2B)
     dedup_elapsed = 0.0
@@ -184,10 +274,15 @@ def main():
         fence()
         dedup_elapsed = (time.perf_counter() - t1) / 2
         model.cfg_mode, model.dedup_dropped_rows = args.cfg_mode, False
+    rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed, dedup_elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dedup_elapsed = float(t[0].item()), float(t[1].item())
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)                             # every rank took part in an RCCL collective
+        rccl_ranks = int(ones.item())
+        assert rccl_ranks == dist.get_world_size()
 
     if rank == 0:
         images = args.bs * world * args.steps
@@ -196,6 +291,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_denoise_step': elapsed / args.steps / args.s_step * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'rccl_ranks': rccl_ranks,
             'config': {'workload': f'DGM CFG-Unet dim={args.dim} {args.image_size}x{args.image_size} '
                                    f'bs={args.bs}/GPU s_step={args.s_step} cond_scale=3 ' + (
                                        '(BASELINE configs[1])' if (args.dim, args.image_size, args.bs, args.s_step) ==
@@ -203,6 +299,7 @@ def main():
                                        (args.dim, args.image_size, args.bs, args.s_step) == (128, 256, 8, 250) else
                                        '(non-BASELINE configuration)'),
                        'global_batch': args.bs * world, 'sharding': f'samples x{world}, no data-path collective',
+                       'cfg_mode': args.cfg_mode,
                        'weights': 'seeded random init', 'noise': 'device Philox',
                        'arithmetic': 'fp32 tensors; 3x3 / 1x1 convolutions and the attention projections multiply block-scaled '
                                      'fp16 pieces of the fp32 operands on the matrix cores (3 MFMAs per product block, '
@@ -216,46 +313,66 @@ def main():
                         'was dropped (p = 0.5, CFG:404) equal their null-pass rows and are computed once; bitwise identical '
                         'samples (tests/test_gpu_unet.py::test_fullsize_rows_independent_and_cfg_modes_agree)'}}
         if log:
-            fl3 = ms3 = n3 = 0.0
-            flc = msc = nc = 0.0
-            flx = 0.0                     # executed fp16-MFMA FLOPs: 3 per algorithmic FLOP; the sub-pixel Upsample convs
-            for e0, e1, k, stride, B, ho, wo, cin, cout, ups in log:      # (upsample2 == 2) execute 16 of every 36 taps
-                if k != 3:
-                    continue
-                ms = e0.elapsed_time(e1)
-                fl = 2.0 * 9 * cin * cout * ho * wo * B
-                fl3, ms3, n3 = fl3 + fl, ms3 + ms, n3 + 1
-                flx += fl * 3.0 * (16.0 / 36.0 if ups == 2 else 1.0)
-                if (cin, cout, ho) == (64, 64, args.image_size):
-                    flc, msc, nc = flc + fl, msc + ms, nc + 1
-            ach = fl3 / (ms3 * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-            if os.path.exists(tpath):       # FETCH_SIZE / WRITE_SIZE passes of rocprofv3 over this command
-                with open(tpath) as f:
-                    traffic = json.load(f)
-            res['roofline'] = {
-                'kernel': 'conv_f16x3_kernel<3,3,...> (3x3 conv, implicit GEMM, 3 x v_mfma_f32_16x16x32_f16 per fp32 '
-                          'product block, fp32 accumulate)',
-                'bound': 'mfma', 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': ach / PEAK_FP32_MFMA_TFLOPS,
-                'executed': {'pipe': 'fp16 MFMA (3 executed FLOPs per algorithmic FLOP; the sub-pixel Upsample convs run 16 of '
-                                     'every 36 taps)', 'TFLOP/s': flx / (ms3 * 1e-3) / 1e12,
-                             'peak': PEAK_FP16_MFMA_TFLOPS, 'frac': flx / (ms3 * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS},
-                'traffic': traffic, 'measured_in': roofline_mode,
-                'launches': int(n3), 'avg_launch_us': ms3 / n3 * 1e3,
-                'canonical_64to64_128sq': {'launches': int(nc), 'avg_launch_us': msc / max(nc, 1) * 1e3,
-                                           'TFLOP/s': (flc / (msc * 1e-3) / 1e12) if msc else None,
-                                           'GB/s_algorithmic': (nc * (4.0 * 2 * args.bs * args.image_size ** 2 * 128
-                                                                      + 4 * (9 * 64 * 64 + 3 * 64))
-                                                                / (msc * 1e-3) / 1e9) if msc else None},
-            }
+            res['roofline'] = roofline(log, args)
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args.dim, args.image_size)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline(log, args):
+    """the `roofline` object of the JSON line from the HIP-event log of one batched step (see the module docstring)."""
+    fl3 = ms3 = n3 = 0.0            # stride-1 3x3 launches (the dominant kernel): 3 executed fp16 FLOPs per algorithmic one
+    flc = msc = nc = 0.0            # of those, the canonical 64->64 @ image_size^2 with the GN+SiLU prologue
+    flu = msu = 0.0                 # sub-pixel Upsample convs (16 of every 36 taps executed): reported, not in `frac`
+    for e0, e1, k, stride, B, ho, wo, cin, cout, ups in log:
+        if k != 3:
+            continue
+        ms = e0.elapsed_time(e1)
+        fl = 2.0 * 9 * cin * cout * ho * wo * B
+        if ups == 2:
+            flu, msu = flu + fl, msu + ms
+            continue
+        fl3, ms3, n3 = fl3 + fl, ms3 + ms, n3 + 1
+        if (cin, cout, ho) == (64, 64, args.image_size):
+            flc, msc, nc = flc + fl, msc + ms, nc + 1
+    ach = fl3 / (ms3 * 1e-3) / 1e12
+    peak = PEAK_FP16_MFMA_TFLOPS / F16X3_TERMS
+    rows = 2 * args.bs
+    canon_bytes = 4.0 * rows * args.image_size ** 2 * (64 + 64) + 4 * (9 * 64 * 64 + 3 * 64) + 8 * rows * 64
+    canon_us = msc / max(nc, 1) * 1e3
+    traffic, traffic_src = None, None
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        tpath = os.path.join(ROOT, 'profiles', name)
+        if os.path.exists(tpath):       # FETCH_SIZE / WRITE_SIZE passes of rocprofv3 (tools/profile_round.sh)
+            with open(tpath) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')
+            traffic_src = 'profiles/' + name
+            break
+    return {
+        'kernel': 'conv_f16x3_kernel<3,3,1,0,...> (stride-1 3x3 conv, implicit GEMM, 3 x v_mfma_f32_16x16x32_f16 per fp32 '
+                  'product block, fp32 accumulate)',
+        'bound': 'mfma', 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak,
+        'peak_note': 'algorithmic TFLOP/s; peak = 2500 dense fp16 MFMA TFLOP/s / 3 executed FLOPs per algorithmic FLOP',
+        'executed': {'pipe': 'fp16 MFMA', 'TFLOP/s': ach * F16X3_TERMS, 'peak': PEAK_FP16_MFMA_TFLOPS,
+                     'frac': ach * F16X3_TERMS / PEAK_FP16_MFMA_TFLOPS},
+        'vs_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,
+        'traffic': traffic, 'traffic_source': traffic_src,
+        'traffic_note': 'HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, averaged over the '
+                        '3x3 launches of a batched step); from the committed profile, not measured by this run',
+        'measured_in': 'one extra untimed step, cfg_mode=batched, HIP events on the launch stream',
+        'launches': int(n3), 'avg_launch_us': ms3 / max(n3, 1) * 1e3,
+        'algorithmic_flop_per_launch': fl3 / max(n3, 1),
+        'canonical_64to64_128sq': {'launches': int(nc), 'avg_launch_us': canon_us,
+                                   'TFLOP/s': (flc / (msc * 1e-3) / 1e12) if msc else None,
+                                   'algorithmic_bytes_per_launch': canon_bytes,
+                                   'GB/s_algorithmic': (canon_bytes / (canon_us * 1e-6) / 1e9) if msc else None},
+        'hbm_frac_canonical': (canon_bytes / (canon_us * 1e-6) / 1e12 / PEAK_HBM_TBS) if msc else None,
+        'subpixel_upsample_convs': {'TFLOP/s_algorithmic': (flu / (msu * 1e-3) / 1e12) if msu else None,
+                                    'note': 'Upsample+conv3x3 in sub-pixel form executes 16 of every 36 taps; kept out of frac'},
+    }
 
 
 if __name__ == '__main__':

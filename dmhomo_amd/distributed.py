@@ -93,17 +93,33 @@ def average_gradients(grads, scale):
 
 def gather_records(imgs_u8, homos, dst=0):
     """per-rank {"imgs": uint8 (b,6,H,W), "homos": f64 (b,3,3)} tensors -> on ``dst`` the rank-ordered
-    concatenation (the record of saveTrainPair, DDP:1678); None elsewhere.  Equal shard sizes."""
+    concatenation (the record of saveTrainPair, DDP:1678); None elsewhere.  Shards may differ in size
+    (shard_bounds hands the first ``total % world`` ranks one sample more): the sizes are exchanged first and the
+    short shards travel padded to the longest."""
     if world_size() == 1:
         return imgs_u8, homos
     world, rank = dist.get_world_size(), dist.get_rank()
-    out_i = [torch.empty_like(imgs_u8) for _ in range(world)] if rank == dst else None
-    out_h = [torch.empty_like(homos) for _ in range(world)] if rank == dst else None
-    dist.gather(imgs_u8, out_i, dst=dst)
-    dist.gather(homos, out_h, dst=dst)
+    nb = torch.tensor([imgs_u8.shape[0]], device=imgs_u8.device, dtype=torch.int64)
+    sizes = [torch.empty_like(nb) for _ in range(world)]
+    dist.all_gather(sizes, nb)
+    sizes = [int(s.item()) for s in sizes]
+    assert homos.shape[0] == imgs_u8.shape[0]
+    bmax = max(sizes)
+
+    def padded(t):
+        if t.shape[0] == bmax:
+            return t.contiguous()
+        out = torch.zeros((bmax,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        out[:t.shape[0]] = t
+        return out
+    pi, ph = padded(imgs_u8), padded(homos)
+    out_i = [torch.empty_like(pi) for _ in range(world)] if rank == dst else None
+    out_h = [torch.empty_like(ph) for _ in range(world)] if rank == dst else None
+    dist.gather(pi, out_i, dst=dst)
+    dist.gather(ph, out_h, dst=dst)
     if rank != dst:
         return None, None
-    return torch.cat(out_i), torch.cat(out_h)
+    return (torch.cat([t[:n] for t, n in zip(out_i, sizes)]), torch.cat([t[:n] for t, n in zip(out_h, sizes)]))
 
 
 class SampleIndexedRng:

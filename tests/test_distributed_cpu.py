@@ -28,7 +28,7 @@ def _worker(rank, world, port, q):
     D.broadcast_module_(d, src=0)
     digest = float(sum(p.double().sum() for p in d.state_dict().values()))
     lo, hi = D.shard_bounds(5, rank, world)
-    total = 6
+    total = 7                                          # uneven shards: rank 0 owns 4 samples, rank 1 owns 3
     slo, shi = D.shard_bounds(total, rank, world)
     imgs = torch.arange(slo, shi, dtype=torch.uint8).reshape(-1, 1, 1, 1).expand(-1, 6, 2, 2).contiguous()
     homos = torch.arange(slo, shi, dtype=torch.float64).reshape(-1, 1, 1).expand(-1, 3, 3).contiguous()
@@ -60,11 +60,35 @@ def test_world2_gloo():
     (r0, d0, b0, gi0, gh0, n0, u0), (r1, d1, b1, gi1, gh1, n1, u1) = res
     assert d0 == d1                                     # identical weights + buffers after the broadcast
     assert b0 == (0, 3) and b1 == (3, 5)                # contiguous, first ranks take the remainder
-    assert gi0 == [0, 1, 2, 3, 4, 5] and gh0 == [0., 1., 2., 3., 4., 5.] and gi1 is None
+    assert gi0 == [0, 1, 2, 3, 4, 5, 6] and gh0 == [0., 1., 2., 3., 4., 5., 6.] and gi1 is None
     from dmhomo_amd import distributed as D
-    full = D.SampleIndexedRng(7, range(0, 6), torch.device('cpu'))
-    assert torch.equal(torch.tensor(n0 + n1), full.randn((6, 2, 3), torch.device('cpu')))
-    assert torch.equal(torch.tensor(u0 + u1), full.uniform(6, torch.device('cpu')))
+    full = D.SampleIndexedRng(7, range(0, 7), torch.device('cpu'))
+    assert torch.equal(torch.tensor(n0 + n1), full.randn((7, 2, 3), torch.device('cpu')))
+    assert torch.equal(torch.tensor(u0 + u1), full.uniform(7, torch.device('cpu')))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent starts the ranks itself (README:14 /
+    dgm_sample.py:13-18 start N processes by hand), relays rank 0's single JSON line and returns the children's exit
+    code.  Run here in the script's test-only CPU plumbing mode (gloo; the sampling step has no CPU path)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['DMH_BENCH_PLUMBING_TEST'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--device', 'cpu', '--bs', '3',
+                        '--steps', '2', '--warmup', '0'], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['rccl_ranks'] == 2 and res['records_in_rank_order'] and res['global_batch'] == 6
+    # outside the test the CPU mode refuses to run, and a failing child makes the launcher exit non-zero
+    env.pop('DMH_BENCH_PLUMBING_TEST')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--device', 'cpu'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and 'test-only plumbing mode' in r.stderr
 
 
 def test_shard_bounds_cover():
