@@ -308,8 +308,8 @@ static int launch_conv(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
 // 3x3 tiling variants (development knob DMH_CONV3_VARIANT, read once; the default is the measured best):
 //   0..3  conv_igemm_kernel   (KC,TH) = (32,16) (16,16) (32,8) (16,8)
 //   6     conv_wino_kernel    Winograd F(2x2,3x3), 8x16 pixels x 64 cout per workgroup
-//   7     conv_bf16x3_kernel  direct implicit GEMM on the bf16 matrix cores, fp32 carried as 3 bf16 pieces
-//   8     conv_wino_bf16x3_kernel  Winograd F(2x2,3x3) on the bf16 matrix cores, fp32 carried as 3 bf16 pieces
+//   (7, 8: the bf16-piece direct / Winograd kernels of round 1 were measured slower than 9 on every shape and are no
+//    longer part of the library — DESIGN.md 3.1 keeps their numbers, the git history their sources)
 //   9     conv_f16x3_kernel   direct implicit GEMM on the fp16 matrix cores, block-scaled 2 x 3 fp16 pieces
 #define DMH_CONV3_DEFAULT 9
 static int conv3_variant() {
@@ -317,7 +317,7 @@ static int conv3_variant() {
   if (v < 0) {
     const char* e = getenv("DMH_CONV3_VARIANT");
     v = e ? atoi(e) : DMH_CONV3_DEFAULT;
-    if (v < 0 || v > 9 || v == 4 || v == 5) v = DMH_CONV3_DEFAULT;
+    if (v < 0 || v > 9 || v == 4 || v == 5 || v == 7 || v == 8) v = DMH_CONV3_DEFAULT;
   }
   return v;
 }
@@ -355,8 +355,6 @@ extern "C" int dmh_conv_tiles(int Hout, int Wout, int KH, int stride) {
 
 extern "C" int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW) {
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack_floats(Cout, C0, C1);
-  if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack_floats(Cout, C0, C1, KH, KW);
-  if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack_floats(Cout, C0, C1);
   if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1) || use_f16x3_s2d(KH, 2, C0, C1))
     return dmh_f16x3_pack_floats(Cout, C0, C1, KH, KW);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
@@ -370,8 +368,6 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
   DMH_REQUIRE(KH == KW && (KH == 1 || KH == 2 || KH == 3 || KH == 4 || KH == 7),
               "dmh_pack_conv_weight: unsupported kernel %dx%d", KH, KW);
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
-  if (KH == 3 && conv3_variant() == 7) return dmh_bf16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
-  if (KH == 3 && conv3_variant() == 8) return dmh_winobx_pack(w, wpack, Cout, C0, C1, (hipStream_t)stream);
   if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1) || use_f16x3_s2d(KH, 2, C0, C1))
     return dmh_f16x3_pack(w, wpack, Cout, C0, C1, KH, KW, (hipStream_t)stream);
   const int stride = (KH == 4 || KH == 2) ? 2 : 1;
@@ -425,8 +421,6 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 2: return launch_conv<3, 3, 1, 0, 32, 8, 16, 3>(d, Hout, Wout, st);
         case 3: return launch_conv<3, 3, 1, 0, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
-        case 7: return dmh_bf16x3_launch3(d, Hout, Wout, st);
-        case 8: return dmh_winobx_launch(d, Hout, Wout, st);
         case 9: return dmh_f16x3_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 0, 32, 16, 16, 2>(d, Hout, Wout, st);
       }
@@ -436,8 +430,6 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
         case 2: return launch_conv<3, 3, 1, 1, 32, 8, 16, 3>(d, Hout, Wout, st);
         case 3: return launch_conv<3, 3, 1, 1, 16, 8, 16, 4>(d, Hout, Wout, st);
         case 6: return dmh_wino_launch(d, Hout, Wout, st);
-        case 7: return dmh_bf16x3_launch3(d, Hout, Wout, st);
-        case 8: return dmh_winobx_launch(d, Hout, Wout, st);
         case 9: return dmh_f16x3_launch(d, Hout, Wout, st);
         default: return launch_conv<3, 3, 1, 1, 32, 16, 16, 2>(d, Hout, Wout, st);
       }

@@ -61,10 +61,6 @@ int64_t dmh_wino_pack_floats(int Cout, int C0, int C1);
 int dmh_wino_pack(const float* w, float* wpack, int Cout, int C0, int C1, hipStream_t st);
 int dmh_wino_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 
-// bf16x3 split path (conv_bf16x3.hip)
-int64_t dmh_bf16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW);
-int dmh_bf16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st);
-int dmh_bf16x3_launch3(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 
 // fp16 split path: two activation pieces x three weight planes, block-scaled (conv_f16x3.hip)
 int64_t dmh_f16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW);
@@ -74,10 +70,6 @@ int64_t dmh_f16x3_up2_pack_floats(int Cout, int C0);
 int dmh_f16x3_up2_pack(const float* w, float* wpack, int Cout, int C0, hipStream_t st);
 int dmh_f16x3_launch_up2(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 
-// Winograd on the bf16 matrix cores, fp32 carried as three bf16 pieces (conv_wino_bf16x3.hip)
-int64_t dmh_winobx_pack_floats(int Cout, int C0, int C1);
-int dmh_winobx_pack(const float* w, float* wpack, int Cout, int C0, int C1, hipStream_t st);
-int dmh_winobx_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 
 // Second half of every conv epilogue: an LDS slab holds rows = output pixels x 64 channels (pitch EP);
 // each wave turns 32 slab rows into NHWC float4 stores: + bias, + residual (optionally through

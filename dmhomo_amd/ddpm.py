@@ -307,9 +307,10 @@ class EMA(nn.Module):
                 mod._dmh_epoch = getattr(mod, '_dmh_epoch', 0) + 1
 
     def copy_params_from_model_to_ema(self):
-        from . import ops
+        """ema_pytorch copies with ``.copy_()``: bit-exact, and a NaN / Inf left in the EMA copy does not survive it
+        (a lerp with decay 0 would keep it)."""
         for pe, po in self._pairs():
-            ops.ema_(pe.data, po.data, 0.)
+            pe.data.copy_(po.data)
         self._bump()
 
     def update(self):
@@ -339,10 +340,17 @@ class EMA(nn.Module):
         return out
 
     def load_state_dict(self, sd, strict=True):
+        """accepts an ema_pytorch.EMA state_dict: ``ema_model.<key>``, optionally ``online_model.<key>`` (absent with
+        include_online_model=False or in a stripped DGM.pt), ``initted``, ``step``.  Trainer.load has already put
+        data['model'] into the online model; whether the EMA copy needs storage of its own is decided against THOSE
+        weights, so an EMA-only checkpoint can never overwrite the online weights through the shared module."""
         ema = {k[len('ema_model.'):]: v for k, v in sd.items() if k.startswith('ema_model.')}
         online = {k[len('online_model.'):]: v for k, v in sd.items() if k.startswith('online_model.')}
-        if online and any(not torch.equal(ema[k].cpu(), v.cpu()) for k, v in online.items() if k in ema):
-            self._own_copy()              # a checkpoint from a trained run: the two copies differ
+        if self.ema_model is self.online_model and ema:
+            cur = self.online_model.state_dict()
+            if any(k in cur and (cur[k].shape != v.shape or not torch.equal(cur[k].detach().cpu(), v.detach().cpu()))
+                   for k, v in ema.items()):
+                self._own_copy()          # a checkpoint from a trained run: the two copies differ
         if 'step' in sd:
             self.step.fill_(int(sd['step']))
         if 'initted' in sd:
@@ -405,6 +413,15 @@ class Trainer(object):
         import torch.distributed as dist
         on = dist.is_available() and dist.is_initialized()
         rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)     # each rank reads its own slice
+        # accelerate's Accelerator(split_batches=...) (DDP:1721-1722): True (the reference's default) = train_batch_size is
+        # the GLOBAL batch, each process takes 1/world of every batch; False = every process takes train_batch_size
+        self.split_batches = bool(split_batches)
+        if self.split_batches and world > 1:
+            if train_batch_size % world != 0:
+                raise ValueError(f'train_batch_size ({train_batch_size}) must be a round multiple of the number of '
+                                 f'processes ({world}) with split_batches=True (accelerate raises the same)')
+            train_batch_size //= world
+        self.rank_batch_size = train_batch_size
         if isinstance(folder, (str, os.PathLike)) and os.path.isfile(os.path.join(str(folder), 'BasesHomo_small.npy')):
             from .dataset import UnHomoTrainData, ConditionLoader                       # DDP:1735-1752
             self.ds = UnHomoTrainData(folder, self.image_size, augment_horizontal_flip=augment_horizontal_flip,

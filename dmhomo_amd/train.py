@@ -494,8 +494,19 @@ class TrainStep:
 
     def ensure_fresh(self):
         """re-pack when something other than ``apply`` changed the parameters (an external optimiser, load_state_dict)"""
+        self.params = dict(self.unet.named_parameters())         # a re-materialised Parameter is a new object
         sig = self._signature()
         if sig != self._sig:
+            if tuple(a for a, _ in sig) != tuple(a for a, _ in self._sig):
+                # storage moved (diffusion.to() / .float(), a cloned or re-created parameter): the captured re-pack graph
+                # reads the OLD pointers — drop it (re-captured on the next refresh); Adam moments follow the parameters
+                if self._repack_graph is not False:
+                    self._repack_graph = None
+                for st in (self._m, self._v):
+                    if st is not None:
+                        for k, p in self.params.items():
+                            if st[k].device != p.device:
+                                st[k] = st[k].to(p.device)
             self.unet._dmh_epoch = getattr(self.unet, '_dmh_epoch', 0) + 1
             self.refresh()
             self._sig = sig

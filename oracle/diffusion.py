@@ -283,6 +283,27 @@ def ddp_ddim_sample(sd, buf, shape, *, sampling_timesteps, objective='pred_noise
     return img
 
 
+def ddp_interpolate(sd, buf, x1, x2, t=None, lam=0.5, *, rng=None, **kw):
+    """D10, DDP:737-754: q_sample both ends at step t (two randn_like draws, x1's first), blend
+    ``(1 - lam) * xt1 + lam * xt2`` in that op order, then p_sample down from t-1 to 0.
+    The reference's loop (DDP:748-752) hands p_sample a (b,) TENSOR where it takes ``t: int`` (DDP:648: ``torch.full``
+    rejects it) and assigns p_sample's (pred_img, x_start) tuple back to ``img``; it therefore raises for every t > 0.
+    The evident intent — python-int steps, carry pred_img — is restated here; for t = 0 (no loop) this is the
+    reference's own result (tests/golden/interpolate.npz holds both: `t0.*` from the reference's interpolate as it
+    stands, `t3.*` from the reference's q_sample / p_sample called in this chain)."""
+    rng = rng or TorchRng()
+    T = buf['betas'].shape[0]
+    t = T - 1 if t is None else t
+    assert x1.shape == x2.shape
+    tb = torch.full((x1.shape[0],), t, dtype=torch.long)
+    xt1 = q_sample(buf, x1, tb, rng.randn(x1.shape))
+    xt2 = q_sample(buf, x2, tb, rng.randn(x2.shape))
+    img = (1 - lam) * xt1 + lam * xt2
+    for i in reversed(range(0, t)):
+        img, _ = ddp_p_sample(sd, buf, img, i, rng=rng, **kw)
+    return img
+
+
 # ------------------------------------------------------------------ D9
 def q_sample(buf, x_start, t, noise):
     """CFG:738-742."""

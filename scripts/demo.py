@@ -44,7 +44,7 @@ def main():
     total = (data_num * epoch) // train_batch_size
     if rank == 0:
         print(f'total steps are: {total}')
-    trainer = Trainer(diffusion, args.data, train_batch_size=max(1, train_batch_size // world), train_lr=1e-4 * 10 / 2,
+    trainer = Trainer(diffusion, args.data, train_batch_size=train_batch_size, train_lr=1e-4 * 10 / 2,
                       train_num_steps=args.steps or total, gradient_accumulate_every=1, ema_decay=0.995, amp=False,
                       results_folder=args.results, save_and_sample_every=1000, num_samples=9,
                       augment_horizontal_flip=False)

@@ -40,6 +40,15 @@ def _worker(rank, world, port, q):
     grads = {'b.weight': torch.full((2, 3), float(rank + 1)), 'a.bias': torch.arange(4.) * (rank + 1)}
     avg = D.average_gradients(grads, lambda flat, sc: flat * sc)
     assert torch.equal(avg['b.weight'], torch.full((2, 3), 1.5)) and torch.equal(avg['a.bias'], torch.arange(4.) * 1.5)
+    # accelerate's split_batches=True (the reference's default, DDP:1721-1722): train_batch_size is the GLOBAL batch
+    from dmhomo_amd import ddpm
+    assert ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=6).rank_batch_size == 3
+    assert ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=6, split_batches=False).rank_batch_size == 6
+    try:
+        ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=5)
+        raise AssertionError('an indivisible global batch must be refused')
+    except ValueError:
+        pass
     q.put((rank, digest, (lo, hi), None if gi is None else gi[:, 0, 0, 0].tolist(),
            None if gh is None else gh[:, 0, 0].tolist(), n1.tolist(), u1.tolist()))   # plain lists: no shm fds
     torch.distributed.barrier()

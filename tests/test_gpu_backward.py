@@ -242,7 +242,7 @@ def test_unet_backward_full_width_ragged_vs_autograd():
             print(f'[parity] unet64 bwd {k}: rel_to_max={r:.3e}')
         worst = max(worst, r)
     print(f'[parity] unet64 bwd (24x24): {len(pnames)} parameter gradients, worst rel_to_max={worst:.3e}')
-    assert worst < 2e-3, worst
+    assert worst < 6e-5, worst          # measured 5.8e-6
 
 
 def test_unet_backward_vs_autograd():
@@ -284,7 +284,7 @@ def test_unet_backward_vs_autograd():
             print(f'[parity] unet bwd {k}: rel_to_max={r:.3e} ref_absmax={ref[k].abs().max().item():.3e}')
         worst = max(worst, r)
     print(f'[parity] unet bwd: {len(pnames)} parameter gradients, worst rel_to_max={worst:.3e}')
-    assert worst < 2e-3, worst
+    assert worst < 6e-5, worst          # measured 5.8e-6
 
 
 # ----------------------------------------------------------------------------------------------- training step
@@ -388,7 +388,7 @@ def test_train_step_gradients_vs_reference(golden_dir):
     clip = ts.apply(grads)
     print(f'[parity] train step: worst gradient rel_to_max={worst:.3e}; grad norm {clip[0].item():.6f} '
           f'want {float(gd["grad_norm"]):.6f}')
-    assert worst < 1e-3
+    assert worst < 6e-5, worst           # measured 5.8e-6
     assert abs(clip[0].item() - float(gd['grad_norm'])) <= 1e-4 * float(gd['grad_norm'])
 
 
@@ -408,6 +408,35 @@ def test_train_trajectory_vs_reference(golden_dir):
     out2, _ = ts.ut.forward(draws['noise'], draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(),
                             torch.ones(3, dtype=torch.uint8, device=img.device))
     assert (out - out2).abs().max().item() < 2e-4 * out2.abs().max().item()
+
+
+def test_train_step_follows_moved_parameter_storage(golden_dir):
+    """a parameter whose storage moves between two optimiser steps (p.data = clone(), what .to() / .float() /
+    load-by-assignment do) must be re-packed from its NEW storage: the re-pack HIP graph captured on the first step
+    holds the old pointers and may not be replayed (the old storage is overwritten with NaN here to make a stale read
+    visible).  The trajectory must equal the one of an undisturbed twin bitwise."""
+    gd, m, d, ts, img, classes, draws = _train_setup(golden_dir, lr=1e-3, accum=1)
+    gd2, m2, d2, ts2, img2, classes2, draws2 = _train_setup(golden_dir, lr=1e-3, accum=1)
+    a1, b1 = ts.step([(img, classes)], draws=[draws]), ts2.step([(img2, classes2)], draws=[draws2])
+    assert float(a1) == float(b1)
+    old = []
+    with torch.no_grad():
+        for p in m.parameters():
+            stale = p.data
+            p.data = stale.clone()
+            old.append(stale)
+        for stale in old:
+            stale.fill_(float('nan'))
+    for i in range(2):
+        a, b = ts.step([(img, classes)], draws=[draws]), ts2.step([(img2, classes2)], draws=[draws2])
+        assert float(a) == float(b), (i, float(a), float(b))
+    for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p.detach(), q.detach()), k
+    # the sampling engine follows too
+    x = draws['noise']
+    o1 = m(x, draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(), cond_drop_prob=0.)
+    o2 = m2(x, draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(), cond_drop_prob=0.)
+    assert torch.isfinite(o1).all() and torch.equal(o1, o2)
 
 
 def test_trainer_train_loop_and_checkpoint(golden_dir, tmp_path):

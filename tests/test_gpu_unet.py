@@ -1,9 +1,12 @@
 """-m gpu: the UNets and samplers end to end (HIP path through the reference-shaped classes) against
 the CPU oracle and the golden vectors captured from the reference.
 
-Tolerances (fp32, different accumulation order than oneDNN):
-  one UNet forward      rtol 1e-3 / atol 2e-4 on O(1) activations   (measured error is printed)
-  S-step sampler output atol 2e-3 on the [0,1] image, uint8 export within +-1 LSB
+Tolerances: <= 10x the error measured on MI355X (fp32, different accumulation order than oneDNN; the measured
+numbers are printed as [parity] lines and recorded in DESIGN.md §4), relative to each tensor's own scale:
+  per-layer activations       2e-5 of the layer's max |x|     (measured 1.1e-6 .. 3.1e-6)
+  one UNet forward, output    2e-5 of max |out|               (measured 1.9e-6)
+  S-step sampler output       4e-4 abs on the [0,1] image     (measured 1.3e-5 at S=4 tiny, 3.7e-5 at S=4 full size),
+                              uint8 export within +-1 LSB
 """
 import json
 import os
@@ -12,11 +15,14 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import dev, nchw, close, report, rand, ReplayDeviceRng
+from gpu_util import dev, nchw, close, close_rel, report, rand, ReplayDeviceRng
 from detweights import det_state_dict, shapes_of
 from oracle import unet as OU, diffusion as OD
 
 pytestmark = pytest.mark.gpu
+
+LAYER_REL = 2e-5        # per-layer activation error / max |activation|   (measured <= 3.1e-6)
+OUT_REL = 2e-5          # UNet output error / max |output|                (measured 1.9e-6)
 
 
 def load(golden_dir, name):
@@ -60,16 +66,16 @@ def test_unet_cfg_tiny_vs_golden(golden_dir):
         if 'tap.' + k in gd:
             a, r = report('tap ' + k, nchw(v), T(gd['tap.' + k]))
             worst = max(worst, r)
-    assert worst < 1e-3, worst
-    close('cfg tiny cond', out.cpu(), T(gd['out_cond']), rtol=1e-3, atol=2e-4)
+    assert worst < LAYER_REL, worst
+    close_rel('cfg tiny cond', out.cpu(), T(gd['out_cond']), OUT_REL)
     out = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=1.)
-    close('cfg tiny null', out.cpu(), T(gd['out_null']), rtol=1e-3, atol=2e-4)
+    close_rel('cfg tiny null', out.cpu(), T(gd['out_null']), OUT_REL)
     m.rng = ReplayDeviceRng([torch.where(T(gd['keep_half']), 0.25, 0.75)])     # uniform draw reproducing keep
     out = m(g(x), g(t), g(c), g(rf), g(mk))
-    close('cfg tiny half', out.cpu(), T(gd['out_half']), rtol=1e-3, atol=2e-4)
+    close_rel('cfg tiny half', out.cpu(), T(gd['out_half']), OUT_REL)
     m.rng = ReplayDeviceRng([torch.where(T(gd['keep_scale3']), 0.25, 0.75)])
     out = m.forward_with_cond_scale(g(x), g(t), g(c), rgb_flow=g(rf), mask=g(mk), cond_scale=3.)
-    close('cfg tiny scale3', out.cpu(), T(gd['out_scale3']), rtol=1e-3, atol=5e-4)
+    close_rel('cfg tiny scale3', out.cpu(), T(gd['out_scale3']), 3 * OUT_REL)     # 3*cond - 2*null: errors add up x5
 
 
 @pytest.mark.parametrize('tag', ['nosc', 'sc'])
@@ -78,10 +84,10 @@ def test_unet_ddp_tiny_vs_golden(golden_dir, tag):
     m, sd = make_ddp(8, tag == 'sc')
     x, xs, t = T(gd['x']), T(gd['x_self_cond']), T(gd['t'])
     if tag == 'sc':
-        close('ddp sc', m(g(x), g(t), g(xs)).cpu(), T(gd['sc.out']), rtol=1e-3, atol=2e-4)
-        close('ddp sc default', m(g(x), g(t)).cpu(), T(gd['sc.out_default']), rtol=1e-3, atol=2e-4)
+        close_rel('ddp sc', m(g(x), g(t), g(xs)).cpu(), T(gd['sc.out']), OUT_REL)
+        close_rel('ddp sc default', m(g(x), g(t)).cpu(), T(gd['sc.out_default']), OUT_REL)
     else:
-        close('ddp nosc', m(g(x), g(t)).cpu(), T(gd['nosc.out']), rtol=1e-3, atol=2e-4)
+        close_rel('ddp nosc', m(g(x), g(t)).cpu(), T(gd['nosc.out']), OUT_REL)
 
 
 def _cond_inputs(B, S, seed):
@@ -106,8 +112,8 @@ def test_unet_cfg_fullsize_vs_oracle():
     for k in rtaps:
         a, r = report('full ' + k, nchw(taps[k]), rtaps[k])
         worst = max(worst, r)
-    assert worst < 1e-3, worst
-    close('cfg full out', out.cpu(), ref, rtol=1e-3, atol=2e-4)
+    assert worst < LAYER_REL, worst
+    close_rel('cfg full out', out.cpu(), ref, OUT_REL)
 
 
 @pytest.mark.parametrize('size,B', [(40, 3), (72, 1)])
@@ -125,8 +131,8 @@ def test_unet_cfg_ragged_sizes_vs_oracle(size, B):
         ref = OU.cfg_unet_forward(sd, x, t, c, rf, mk, keep, taps=rtaps)
     out = m._run(g(x), g(t), g(c), g(rf), g(mk), [g(keep.to(torch.uint8))], taps=taps)
     worst = max(report(f'ragged{size} ' + k, nchw(taps[k]), rtaps[k])[1] for k in rtaps)
-    assert worst < 1e-3, worst
-    close(f'cfg ragged {size} out', out.cpu(), ref, rtol=1e-3, atol=2e-4)
+    assert worst < LAYER_REL, worst
+    close_rel(f'cfg ragged {size} out', out.cpu(), ref, OUT_REL)
 
 
 def test_unet_rows_are_independent():
@@ -200,9 +206,9 @@ def test_ddim_trace_vs_golden(golden_dir, obj):
     from dmhomo_amd import ops
     rgbn = ops.affine(g(T(gd['rgb_flow01'])), 2., -1.)
     img, mk, fl = d.ddim_sample(g(T(gd['classes'])), rgbn, g(T(gd['flow'])), g(T(gd['mask'])), shape, trace=trace)
-    tol = 2e-3 if obj == 'pred_x0' else 2e-2          # pred_noise / pred_v divide by sqrt_recipm1 ~ 5e-5..1 (x20291 gain)
+    tol = 3e-4                                        # measured: x_start <= 3.9e-5, img <= 1.4e-5 (all three objectives)
     for i, st in enumerate(trace):
-        report(f'{obj} x_start{i}', st['x_start'].cpu(), T(gd[f'{obj}.x_start{i}']))
+        close(f'{obj} x_start{i}', st['x_start'].cpu(), T(gd[f'{obj}.x_start{i}']), rtol=0, atol=tol)
     close(f'{obj} img', img.cpu(), T(gd[f'{obj}.img']), rtol=0, atol=tol)
     assert d.rng.i == 8
     # sample() = rgb_flow*2-1 + ddim_sample, same result
@@ -220,15 +226,19 @@ def test_ddpm_trace_vs_golden(golden_dir, tag):
     m, sd = make_ddp(8, tag == 'sc')
     d = ddpm.GaussianDiffusion(m, image_size=16, timesteps=10, objective='pred_noise').to(dev())
     d.rng = ReplayDeviceRng([gd[f'{tag}.ddpm.draw{i}'] for i in range(10)])
-    close(f'ddpm {tag}', d.sample(batch_size=2).cpu(), T(gd[f'{tag}.ddpm.img']), rtol=1e-3, atol=2e-3)
+    # 10 ancestral steps with pred_noise (x_start = a*x - b*eps, gains up to ~20 at the first steps): measured 1.1e-5
+    # (nosc) / 1.2e-4 (sc: the self-conditioning input feeds each step's error back into the network)
+    close(f'ddpm {tag}', d.sample(batch_size=2).cpu(), T(gd[f'{tag}.ddpm.img']), rtol=0, atol=1e-3 if tag == 'sc' else 1e-4)
     d2 = ddpm.GaussianDiffusion(m, image_size=16, timesteps=10, sampling_timesteps=4, objective='pred_x0').to(dev())
     d2.rng = ReplayDeviceRng([gd[f'{tag}.ddim.draw{i}'] for i in range(4)])
-    close(f'ddp ddim {tag}', d2.sample(batch_size=2).cpu(), T(gd[f'{tag}.ddim.img']), rtol=1e-3, atol=0.5)
+    got, want = d2.sample(batch_size=2).cpu(), T(gd[f'{tag}.ddim.img'])
+    close(f'ddp ddim {tag} image channel', got[:, :-2], want[:, :-2], rtol=0, atol=2e-4)       # [0, 1]
+    close(f'ddp ddim {tag} flow channels (x512)', got[:, -2:], want[:, -2:], rtol=0, atol=6e-2)  # measured 6.7e-3 of +-512
     if tag == 'nosc':
         d.rng = ReplayDeviceRng([gd['p_sample.noise']])
         img, xs = d.p_sample(g(T(gd['p_sample.x'])), 5)
-        close('p_sample img', img.cpu(), T(gd['p_sample.img']), rtol=1e-3, atol=1e-3)
-        close('p_sample x_start', xs.cpu(), T(gd['p_sample.x_start']), rtol=1e-3, atol=1e-3)
+        close('p_sample img', img.cpu(), T(gd['p_sample.img']), rtol=0, atol=5e-5)
+        close('p_sample x_start', xs.cpu(), T(gd['p_sample.x_start']), rtol=0, atol=5e-5)
 
 
 def test_sample_fullsize_vs_oracle_and_properties():
@@ -252,11 +262,103 @@ def test_sample_fullsize_vs_oracle_and_properties():
                                   objective='pred_x0', rng=rec)
     d.rng = ReplayDeviceRng(rec.draws)
     img, mk2, fl2 = d.sample(g(c), g(rf01), g(flow), g(mk))
-    close('sample full', img.cpu(), ref, rtol=0, atol=2e-3)
+    close('sample full', img.cpu(), ref, rtol=0, atol=4e-4)          # measured 3.7e-5
     u8 = ops.to_uint8(img).cpu().numpy().astype(np.int32)
     ru8 = (ref.numpy() * 255).astype(np.uint8).astype(np.int32)
     assert np.abs(u8 - ru8).max() <= 1
     assert float(img.min()) >= 0 and float(img.max()) <= 1
+
+
+@pytest.mark.parametrize('S', [16, 32])
+def test_ddim_trace_s32_vs_golden(golden_dir, S):
+    """F5 at the README's s_step = 32, T = 1000 (tests/golden/make_golden_r2.py): the reference's own 32-step sample()
+    run replayed draw for draw (64 draws), per-step x_start and the final image"""
+    from dmhomo_amd import cfg
+    gd = load(golden_dir, 'ddim_trace_s32')
+    m, sd = make_cfg(8)
+    d = cfg.GaussianDiffusion(m, image_size=S, timesteps=1000, sampling_timesteps=32, objective='pred_x0').to(dev())
+    d.rng = ReplayDeviceRng([gd[f's{S}.draw{i}'] for i in range(64)])
+    trace = []
+    from dmhomo_amd import ops
+    rgbn = ops.affine(g(T(gd[f's{S}.rgb_flow01'])), 2., -1.)
+    img, _, _ = d.ddim_sample(g(T(gd[f's{S}.classes'])), rgbn, g(T(gd[f's{S}.flow'])), g(T(gd[f's{S}.mask'])),
+                              (2, 6, S, S), trace=trace)
+    assert d.rng.i == 64 and len(trace) == 32
+    drift = [float((st['x_start'].cpu() - T(gd[f's{S}.x_start{i}'])).abs().max()) for i, st in enumerate(trace)]
+    print(f'[parity] ddim S=32 {S}x{S}: per-step max|x_start - reference| = ' + ' '.join(f'{e:.1e}' for e in drift))
+    assert max(drift) <= 4e-4, max(drift)
+    close(f'ddim S=32 {S}x{S} img', img.cpu(), T(gd[f's{S}.img']), rtol=0, atol=4e-4)
+
+
+def _fullsize_s32_inputs(B):
+    _, rf, mk = _cond_inputs(B, 128, 700)
+    return (rf + 1) / 2, rand((B, 2, 128, 128), 703), mk, torch.zeros(B, dtype=torch.long)
+
+
+def test_sample_fullsize_s32_vs_oracle():
+    """BASELINE configs[1] at its real depth: dim 64, 128x128, timesteps = 1000, sampling_timesteps = 32 (the hot loop
+    CFG:683-707 as dgm_sample.py:34 drives it), B = 2, against the oracle on replayed noise.  Error growth over 32
+    full-width denoise steps is what this pins (SURVEY §7 'hard parts'); the per-step drift is printed."""
+    from dmhomo_amd import cfg, ops
+    m, sd = make_cfg(64)
+    d = cfg.GaussianDiffusion(m, image_size=128, timesteps=1000, sampling_timesteps=32, objective='pred_x0').to(dev())
+    B = 2
+    rf01, flow, mk, c = _fullsize_s32_inputs(B)
+    torch.manual_seed(99)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rec = OD.RecordRng()
+    rtrace = []
+    with torch.no_grad():
+        ref, _, _ = OD.cfg_sample(sd, OD.schedule_buffers(1000, 'cosine'), c, rf01, flow, mk, image_size=128, channels=6,
+                                  sampling_timesteps=32, objective='pred_x0', rng=rec, trace=rtrace)
+    assert len(rec.draws) == 64
+    d.rng = ReplayDeviceRng(rec.draws)
+    trace = []
+    rgbn = ops.affine(g(rf01), 2., -1.)
+    img, _, _ = d.ddim_sample(g(c), rgbn, g(flow), g(mk), (B, 6, 128, 128), trace=trace)
+    drift = [float((a['x_start'].cpu() - b['x_start']).abs().max()) for a, b in zip(trace, rtrace)]
+    print('[parity] sample S=32 full size: per-step max|x_start - oracle| = ' + ' '.join(f'{e:.1e}' for e in drift))
+    close('sample S=32 full', img.cpu(), ref, rtol=0, atol=2e-4)
+    u8 = ops.to_uint8(img).cpu().numpy().astype(np.int32)
+    ru8 = (ref.numpy() * 255).astype(np.uint8).astype(np.int32)
+    assert np.abs(u8 - ru8).max() <= 1
+    assert float(img.min()) >= 0 and float(img.max()) <= 1
+
+
+def test_sample_bs25_s32_rows_match_bs2():
+    """configs[1] at its real batch and depth (bs = 25, s_step = 32, 128x128, the bench's 'streams' CFG mode) with noise
+    keyed by sample index: rows 0-1 are BITWISE the rows of a bs = 2 run (what sample-sharding across GPUs relies on),
+    everything is finite and inside [0, 1]."""
+    from dmhomo_amd import cfg
+    from dmhomo_amd.distributed import SampleIndexedRng
+    m, sd = make_cfg(64)
+    d = cfg.GaussianDiffusion(m, image_size=128, timesteps=1000, sampling_timesteps=32, objective='pred_x0').to(dev())
+    rf01, flow, mk, c = (g(v) for v in _fullsize_s32_inputs(25))
+    outs = {}
+    for B, mode in ((25, 'streams'), (2, 'batched')):
+        m.cfg_mode = mode
+        d.rng = SampleIndexedRng(7, range(B), dev())
+        outs[B], _, _ = d.sample(c[:B], rf01[:B].contiguous(), flow[:B].contiguous(), mk[:B].contiguous())
+    m.cfg_mode = 'batched'
+    assert outs[25].shape == (25, 6, 128, 128) and torch.isfinite(outs[25]).all()
+    assert float(outs[25].min()) >= 0 and float(outs[25].max()) <= 1
+    assert torch.equal(outs[25][:2], outs[2])
+
+
+def test_exact_fp32_conv_variant_in_child_process():
+    """DMH_CONV3_VARIANT=6 — the exact-fp32 Winograd 3x3 path the bench line advertises as the alternative to the
+    fp16-piece kernel — is read once per process, so it is exercised in a fresh child: conv2d kernel parity and the
+    full-size UNet vs the oracle under it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMH_CONV3_VARIANT='6')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        os.path.join(root, 'tests', 'test_gpu_kernels.py') + '::test_conv2d',
+                        os.path.join(root, 'tests', 'test_gpu_unet.py') + '::test_unet_cfg_fullsize_vs_oracle'],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_state_dict_roundtrip_through_trainer(tmp_path):
@@ -315,8 +417,8 @@ def test_unet_stress_geometry_vs_oracle():
         ref = OU.cfg_unet_forward(sd, x, t, c, rf, mk, None, taps=rtaps)
     out = m._run(g(x), g(t), g(c), g(rf), g(mk), [None], taps=taps)
     worst = max(report('stress ' + k, nchw(taps[k]), rtaps[k])[1] for k in ('downs.0.2', 'mid_attn', 'ups.3.3'))
-    assert worst < 1e-3, worst
-    close('stress out', out.cpu(), ref, rtol=1e-3, atol=3e-4)
+    assert worst < LAYER_REL, worst
+    close_rel('stress out', out.cpu(), ref, OUT_REL)
 
 
 def test_unet_ddp_fullsize_vs_oracle():
@@ -326,26 +428,28 @@ def test_unet_ddp_fullsize_vs_oracle():
     t = torch.tensor([12, 907])
     with torch.no_grad():
         ref = OU.ddp_unet_forward(sd, x, t, xs, True)
-    close('ddp full', m(g(x), g(t), g(xs)).cpu(), ref, rtol=1e-3, atol=2e-4)
+    close_rel('ddp full', m(g(x), g(t), g(xs)).cpu(), ref, OUT_REL)
 
 
-@pytest.mark.gpu
-def test_ddp_interpolate_matches_manual_chain():
-    """DDP:737-754 (with pred_img carried, see the docstring): q_sample both ends, blend, p_sample chain"""
-    from dmhomo_amd import ddpm, ops
-    torch.manual_seed(3)
-    m = ddpm.Unet(dim=8, dim_mults=(1, 2), channels=6).cuda()
-    d = ddpm.GaussianDiffusion(m, image_size=16, timesteps=50, sampling_timesteps=50, loss_type='l1',
-                               objective='pred_x0').cuda()
-    x1, x2 = torch.rand(2, 6, 16, 16, device='cuda') * 2 - 1, torch.rand(2, 6, 16, 16, device='cuda') * 2 - 1
-    draws = [torch.randn(2, 6, 16, 16) for _ in range(2 + 4)]
+def test_ddp_interpolate_vs_golden(golden_dir):
+    """D10, DDP:737-754 against the reference: t = 0 is the reference's interpolate as it stands; t = 3 is the
+    reference's own q_sample / p_sample in the chain the method means (it raises for t > 0: see oracle.diffusion.
+    ddp_interpolate) — both from tests/golden/interpolate.npz, replaying the recorded draws"""
+    from dmhomo_amd import ddpm
+    gd = load(golden_dir, 'interpolate')
+    m, sd = make_ddp(8, False)
+    d = ddpm.GaussianDiffusion(m, image_size=16, timesteps=10, objective='pred_noise').to(dev())
+    x1, x2 = g(T(gd['x1'])), g(T(gd['x2']))
+    d.rng = ReplayDeviceRng([gd['t0.draw0'], gd['t0.draw1']])
+    close('interpolate t=0', d.interpolate(x1, x2, t=0, lam=0.25).cpu(), T(gd['t0.out']), rtol=0, atol=2e-6)
+    d.rng = ReplayDeviceRng([gd[f't3.draw{i}'] for i in range(4)])
+    got = d.interpolate(x1, x2, t=3, lam=0.25)
+    assert d.rng.i == 4
+    close('interpolate t=3', got.cpu(), T(gd['t3.out']), rtol=0, atol=1e-4)
+    # and against the oracle's restatement at a different blend / depth
+    draws = [torch.randn(2, 3, 16, 16, generator=torch.Generator().manual_seed(80 + i)) for i in range(2 + 5)]
+    with torch.no_grad():
+        ref = OD.ddp_interpolate(sd, OD.schedule_buffers(10, 'cosine'), x1.cpu(), x2.cpu(), t=6, lam=0.7,
+                                 objective='pred_noise', rng=OD.ReplayRng(draws))
     d.rng = ReplayDeviceRng(draws)
-    got = d.interpolate(x1, x2, t=4, lam=0.25)
-    d.rng = ReplayDeviceRng(draws)
-    tb = torch.full((2,), 4, device='cuda', dtype=torch.long)
-    a, b = d.q_sample(x1, tb), d.q_sample(x2, tb)
-    img = 0.75 * a + 0.25 * b
-    for i in reversed(range(4)):
-        img, _ = d.p_sample(img, i)
-    assert got.shape == x1.shape and torch.isfinite(got).all()
-    torch.testing.assert_close(got, img, rtol=1e-5, atol=1e-5)
+    close('interpolate t=6 vs oracle', d.interpolate(x1, x2, t=6, lam=0.7).cpu(), ref, rtol=0, atol=2e-4)

@@ -128,3 +128,62 @@ def test_ema_decay_schedule():
         assert abs(e.get_current_decay() - want) < 1e-12, (step, e.get_current_decay(), want)
     sd = e.state_dict()
     assert {'initted', 'step', 'online_model.weight', 'ema_model.weight'} <= set(sd)
+
+
+def _ema_shaped_checkpoint(d_online_sd, d_ema_sd, with_online=True, step=1234):
+    """a checkpoint dict shaped like the reference's Trainer.save output (DDP:1786-1802) whose 'ema' entry has the key
+    layout of ema_pytorch.EMA(diffusion_model).state_dict(): 'initted', 'step', 'ema_model.<key>' and —
+    unless the EMA was built with include_online_model=False or the file was stripped — 'online_model.<key>', where
+    <key> runs over GaussianDiffusion.state_dict() ('model.<unet key>' + the 13 schedule buffers)."""
+    ema = {'initted': torch.tensor(True), 'step': torch.tensor(step)}
+    if with_online:
+        ema.update({'online_model.' + k: v.clone() for k, v in d_online_sd.items()})
+    ema.update({'ema_model.' + k: v.clone() for k, v in d_ema_sd.items()})
+    return {'step': step, 'model': {k: v.clone() for k, v in d_online_sd.items()}, 'opt': None, 'ema': ema,
+            'scaler': None, 'version': '1.0.0'}
+
+
+@pytest.mark.parametrize('with_online', [True, False])
+def test_trainer_load_of_an_ema_pytorch_shaped_checkpoint(tmp_path, meta, with_online):
+    """SURVEY §8f row 3 / DDP:1804-1826: Trainer.load of a checkpoint whose EMA weights differ from the online ones.
+    The online model must end up with data['model'], ``trainer.ema.ema_model`` (what Trainer.sample reads, DDP:1960)
+    with the 'ema_model.' weights, in storage of its own — also when the file carries no 'online_model.' keys."""
+    from detweights import det_state_dict, shapes_of
+    from dmhomo_amd import cfg, ddpm
+
+    def build(seed):
+        m = cfg.Unet(dim=8, channels=6, num_classes=1)
+        m.load_state_dict(det_state_dict(shapes_of(m), seed))
+        return cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=4, objective='pred_x0')
+    online, ema = build(11).state_dict(), build(12).state_dict()
+    assert set(online) == set(meta['diffusion_cfg_dim64_keys'])       # same key set as the reference's dim-64 model
+    torch.save(_ema_shaped_checkpoint(online, ema, with_online), str(tmp_path / 'model-3.pt'))
+    d = build(0)
+    tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=2, results_folder=str(tmp_path))
+    tr.load(3)
+    assert tr.step == 1234 and int(tr.ema.step) == 1234 and bool(tr.ema.initted)
+    for k, v in d.state_dict().items():
+        assert torch.equal(v, online[k]), k                            # online weights: data['model'], untouched by the EMA
+    assert tr.ema.ema_model is not tr.ema.online_model
+    for k, v in tr.ema.ema_model.state_dict().items():
+        assert torch.equal(v, ema[k]), k
+    sd = tr.ema.state_dict()                                           # and it saves back with both prefixes
+    assert torch.equal(sd['ema_model.model.init_conv.weight'], ema['model.init_conv.weight'])
+    assert torch.equal(sd['online_model.model.init_conv.weight'], online['model.init_conv.weight'])
+    # an untrained checkpoint (EMA == online) keeps sharing one copy: a sampling-only run pays for one set of weights
+    torch.save(_ema_shaped_checkpoint(online, online, with_online), str(tmp_path / 'model-4.pt'))
+    d2 = build(0)
+    tr2 = ddpm.Trainer(d2, 'DGM_Conditions', train_batch_size=2, results_folder=str(tmp_path))
+    tr2.load(4)
+    assert tr2.ema.ema_model is tr2.ema.online_model
+
+
+def test_trainer_split_batches_semantics():
+    """accelerate's split_batches (DDP:1721-1722): True = train_batch_size is the global batch"""
+    from dmhomo_amd import cfg, ddpm
+    m = cfg.Unet(dim=8, channels=6, num_classes=1)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=10)
+    tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=6)
+    assert tr.batch_size == 6 and tr.rank_batch_size == 6 and tr.split_batches      # one process: the whole batch
+    tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=6, split_batches=False)
+    assert tr.rank_batch_size == 6

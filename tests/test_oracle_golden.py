@@ -175,6 +175,42 @@ def test_ddim_trace_seeded_stream(golden_dir, meta):
         assert torch.equal(d, T(g[f'pred_x0.draw{i}'])), i
 
 
+@pytest.mark.parametrize('S', [16, 32])
+def test_ddim_trace_s32(golden_dir, meta, S):
+    """F5 at the README's s_step = 32 (tests/golden/make_golden_r2.py): 64 draws, per-step x_start, final image"""
+    g = load(golden_dir, 'ddim_trace_s32')
+    sd = sd_from(meta, 'unet_cfg_tiny')
+    buf = OD.schedule_buffers(1000, 'cosine')
+    draws = [T(g[f's{S}.draw{i}']) for i in range(64)]
+    assert [tuple(d.shape) for d in draws] == [(2, 6, S, S)] + [(2,), (2, 6, S, S)] * 31 + [(2,)]
+    trace = []
+    with torch.no_grad():
+        img, _, _ = OD.cfg_sample(sd, buf, T(g[f's{S}.classes']), T(g[f's{S}.rgb_flow01']), T(g[f's{S}.flow']),
+                                  T(g[f's{S}.mask']), image_size=S, channels=6, sampling_timesteps=32,
+                                  objective='pred_x0', rng=OD.ReplayRng(draws), trace=trace)
+    assert len(trace) == 32
+    for i, st in enumerate(trace):
+        close(st['x_start'], g[f's{S}.x_start{i}'], rtol=1e-3, atol=2e-4)
+    close(img, g[f's{S}.img'], rtol=1e-3, atol=2e-4)
+
+
+# ------------------------------------------------------------------------- D10
+def test_interpolate(golden_dir, meta):
+    """DDP:737-754.  t = 0: the reference's interpolate as it stands; t = 3: the reference's q_sample / p_sample in the
+    chain the method means (the method itself raises for t > 0 — recorded in the fixture)"""
+    g = load(golden_dir, 'interpolate')
+    sd = sd_from(meta, 'unet_ddp_tiny_nosc', seed=1)
+    buf = OD.schedule_buffers(10, 'cosine')
+    x1, x2 = T(g['x1']), T(g['x2'])
+    with torch.no_grad():
+        out0 = OD.ddp_interpolate(sd, buf, x1, x2, t=0, lam=0.25, rng=OD.ReplayRng([T(g['t0.draw0']), T(g['t0.draw1'])]))
+        close(out0, g['t0.out'], rtol=1e-6, atol=1e-6)
+        assert int(g['t3.reference_raises']) == 1
+        out3 = OD.ddp_interpolate(sd, buf, x1, x2, t=3, lam=0.25, objective='pred_noise',
+                                  rng=OD.ReplayRng([T(g[f't3.draw{i}']) for i in range(4)]))
+        close(out3, g['t3.out'])
+
+
 # ------------------------------------------------------------------------- F8
 @pytest.mark.parametrize('obj,lt', [('pred_x0', 'l1'), ('pred_noise', 'l2'), ('pred_v', 'l1')])
 def test_train_forward(golden_dir, meta, obj, lt):
