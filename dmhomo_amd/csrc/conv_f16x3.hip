@@ -310,8 +310,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     {
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {          // st = 2 * tap + (half of the output channels)
+#ifdef DMH_STAMPS
+        if (!(p.ablate & 8))                        // ablation: the weight fragments are loaded once (no B stream)
+#endif
         load_b((st + NB - 1) % NB, step + NB - 1);  // weights of the step NB - 1 ahead
         __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the loads next to their use)
+#ifdef DMH_STAMPS
+        if (!(p.ablate & 16) || st == 0)            // ablation: the A fragments are read once per chunk (no LDS reads)
+#endif
         if ((st & 1) == 0) read_a(st >> 1);
         // g1s = g1 * 2^-11 is derived here (4 packed fp16 multiplies per fragment) instead of being streamed:
         // a third less weight traffic on the CU's 64 B/clk vector-memory path

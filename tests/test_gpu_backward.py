@@ -414,11 +414,12 @@ def test_train_step_follows_moved_parameter_storage(golden_dir):
     """a parameter whose storage moves between two optimiser steps (p.data = clone(), what .to() / .float() /
     load-by-assignment do) must be re-packed from its NEW storage: the re-pack HIP graph captured on the first step
     holds the old pointers and may not be replayed (the old storage is overwritten with NaN here to make a stale read
-    visible).  The trajectory must equal the one of an undisturbed twin bitwise."""
+    visible).  The trajectory must equal the one of an undisturbed twin (to fp32 rounding: the batch-reduction
+    kernels of the backward pass are not bitwise run-to-run reproducible)."""
     gd, m, d, ts, img, classes, draws = _train_setup(golden_dir, lr=1e-3, accum=1)
     gd2, m2, d2, ts2, img2, classes2, draws2 = _train_setup(golden_dir, lr=1e-3, accum=1)
     a1, b1 = ts.step([(img, classes)], draws=[draws]), ts2.step([(img2, classes2)], draws=[draws2])
-    assert float(a1) == float(b1)
+    assert abs(float(a1) - float(b1)) <= 1e-6 * abs(float(b1))
     old = []
     with torch.no_grad():
         for p in m.parameters():
@@ -429,14 +430,15 @@ def test_train_step_follows_moved_parameter_storage(golden_dir):
             stale.fill_(float('nan'))
     for i in range(2):
         a, b = ts.step([(img, classes)], draws=[draws]), ts2.step([(img2, classes2)], draws=[draws2])
-        assert float(a) == float(b), (i, float(a), float(b))
+        assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)), (i, float(a), float(b))
     for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
-        assert torch.equal(p.detach(), q.detach()), k
+        err = (p.detach() - q.detach()).abs().max().item()
+        assert err <= 2e-5 * max(1e-3, q.detach().abs().max().item()), (k, err)     # NaN (a stale read) fails this too
     # the sampling engine follows too
     x = draws['noise']
     o1 = m(x, draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(), cond_drop_prob=0.)
     o2 = m2(x, draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(), cond_drop_prob=0.)
-    assert torch.isfinite(o1).all() and torch.equal(o1, o2)
+    assert torch.isfinite(o1).all() and (o1 - o2).abs().max().item() <= 1e-4 * o2.abs().max().item()
 
 
 def test_trainer_train_loop_and_checkpoint(golden_dir, tmp_path):
