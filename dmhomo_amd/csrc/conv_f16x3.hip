@@ -160,23 +160,33 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   const uint4* wbase = reinterpret_cast<const uint4*>(p.wpack) + (size_t)nt * nsteps * STEP_U4 + lane;
 
   // B fragments of one step = (tap, half of the 64 output channels): [column block][plane g1, g2]; NB buffers rotate
-  // over the steps, so the loads run NB - 1 steps (two for 3x3) ahead of their use
+  // over the steps, so the loads run NB - 1 steps (two for 3x3) ahead of their use.
+  // Stride-1 3x3 convolutions walk their taps COLUMN-major (kx outer, ky inner): the A fragment of tap (ky, kx) for row
+  // block mb is tile row mb + ky shifted by kx columns, so one kx needs the 6 tile rows of the wave once (12 ds_read_b128)
+  // for its three ky — 36 LDS reads per chunk instead of 72.  The packed weight keeps its [tap = ky * 3 + kx] order; only
+  // the order in which the steps are fetched and multiplied changes.
+  constexpr bool ROWREUSE = KH == 3 && KW == 3 && S == 1 && UPS != 3 && UPS != 2;
   constexpr int NSTEP = NTAPS * 2;                  // steps per chunk
   constexpr int NB = (NSTEP % 3 == 0) ? 3 : 2;      // NSTEP % NB == 0: a step's buffer index is static
   uint4 bq[NB][4];
-  auto load_b = [&](int buf, int step) {
-    const uint4* src = wbase + (size_t)(step < nsteps ? step : nsteps - 1) * STEP_U4;
+  auto tap_of = [](int pos) constexpr { return ROWREUSE ? (pos % 3) * 3 + pos / 3 : pos; };   // pos-th tap multiplied
+  auto load_b = [&](int buf, int ch_, int st_) {    // st_ may run past the chunk: the first steps of the next one
+    if (st_ >= NSTEP) {
+      st_ -= NSTEP;
+      ch_ += 1;
+    }
+    if (ch_ >= nchunks) ch_ = nchunks - 1;          // (past the end: a harmless re-load)
+    const uint4* src = wbase + ((size_t)(ch_ * NTAPS + tap_of(st_ >> 1)) * 2 + (st_ & 1)) * STEP_U4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) bq[buf][i] = src[i * 64];
   };
 #pragma unroll
-  for (int i = 0; i < NB - 1; ++i) load_b(i, i);
+  for (int i = 0; i < NB - 1; ++i) load_b(i, 0, i);
 
   // input (halo) tile of one channel chunk: global -> registers, issued one chunk ahead.  Unconditional loads
   // from clamped addresses + a validity mask (see conv.hip) keep them in flight under counted waits.
   const int c4 = tid & 7;
   float4 v[NLOAD];
-  float4 ca, cb;
   int poff[NLOAD], wroff[NLOAD];
   unsigned inside = 0;
 #pragma unroll
@@ -212,27 +222,27 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
         v[i] = ld4(src + ((size_t)(b * p.Hin + yc) * p.Win + xc) * Csrc + c2);
         inside_ch |= (ok ? 1u : 0u) << i;
       }
-      ca = make_float4(1.f, 1.f, 1.f, 1.f);
-      cb = make_float4(0.f, 0.f, 0.f, 0.f);
       return;
     }
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) v[i] = ld4(src + (size_t)poff[i] * Csrc + cc);
-    ca = make_float4(1.f, 1.f, 1.f, 1.f);
-    cb = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.in_coef != nullptr && !s1) {
-      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + cc);
-      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + cc);
-    }
   };
   issue_chunk_loads(0);
   __syncthreads();                              // block-maximum slots are zeroed
 
   int e_run = 16;  // biased exponent of the running block maximum (clamped to [16, 254]); uniform
-  int step = 0;
   for (int ch = 0; ch < nchunks; ++ch) {
     const bool s1c = ch >= p.nch0;
     const bool pro = (p.in_coef != nullptr) && !s1c;
+    // the GroupNorm coefficients of this chunk's channels (L2-resident, 32 B per lane): fetched here rather than with
+    // the halo prefetch, which would keep 8 more registers alive across the whole matrix phase
+    float4 ca = make_float4(1.f, 1.f, 1.f, 1.f), cb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pro) {
+      const int cq = ch * KC + c4 * 4;
+      const int ccq = cq < p.C0 ? cq : 0;
+      ca = ld4(p.in_coef + (size_t)(b * 2 + 0) * p.C0 + ccq);
+      cb = ld4(p.in_coef + (size_t)(b * 2 + 1) * p.C0 + ccq);
+    }
     const bool cvalid = UPS == 2 || (s1c ? ch - p.nch0 : ch) * KC + c4 * 4 < (s1c ? p.C1 : p.C0);
     const unsigned msk = cvalid ? inside_ch : 0u;
     // ---- values of this chunk (prologue applied, padding zeroed) stay in v[]; their largest magnitude -> LDS slot
@@ -297,6 +307,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 
     // A fragments [row block][plane] of one tap (all 32 channels of the chunk: K = 32 per MFMA)
     half8 a[4][2];
+    half8 ar[ROWREUSE ? 5 : 1][2];                  // ROWREUSE: tile rows of the wave at one column shift kx; row r lives in
+                                                    // slot r % 5 (ky = 0 needs rows 0-3, ky = 1 adds row 4, ky = 2 row 5)
     auto read_a = [&](int tap) {
       const unsigned char* at = in_tile + (tap / KW) * ROWP + (tap % KW) * PITCH;
 #pragma unroll
@@ -304,36 +316,56 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) a[mb][pl] = *reinterpret_cast<const half8*>(at + arow[mb] + pl * 64);
     };
+    auto read_rows = [&](int kx, int r0, int r1) {  // tile rows wm * 4 + [r0, r1), columns l15 + kx
+      const unsigned char* at = in_tile + kx * PITCH;
+#pragma unroll
+      for (int r = r0; r < r1; ++r)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          ar[ROWREUSE ? r % 5 : 0][pl] = *reinterpret_cast<const half8*>(at + arow[0] + r * ROWP + pl * 64);
+    };
 #ifdef DMH_STAMPS
     if (!(p.ablate & 2))
 #endif
     {
 #pragma unroll
-      for (int st = 0; st < NSTEP; ++st) {          // st = 2 * tap + (half of the output channels)
+      for (int st = 0; st < NSTEP; ++st) {          // st = 2 * (position in the tap walk) + (half of the output channels)
 #ifdef DMH_STAMPS
         if (!(p.ablate & 8))                        // ablation: the weight fragments are loaded once (no B stream)
 #endif
-        load_b((st + NB - 1) % NB, step + NB - 1);  // weights of the step NB - 1 ahead
+        load_b((st + NB - 1) % NB, ch, st + NB - 1);  // weights of the step NB - 1 ahead
         __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the loads next to their use)
+        const int pos = st >> 1;
 #ifdef DMH_STAMPS
         if (!(p.ablate & 16) || st == 0)            // ablation: the A fragments are read once per chunk (no LDS reads)
 #endif
-        if ((st & 1) == 0) read_a(st >> 1);
+        {
+          if (ROWREUSE) {
+            if ((st & 1) == 0) read_rows(pos / 3, pos % 3 == 0 ? 0 : 3 + pos % 3, 4 + pos % 3);
+          } else if ((st & 1) == 0) {
+            read_a(pos);
+          }
+        }
         // g1s = g1 * 2^-11 is derived here (4 packed fp16 multiplies per fragment) instead of being streamed:
         // a third less weight traffic on the CU's 64 B/clk vector-memory path
         half8 g1s[2];
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
           g1s[nb] = __builtin_bit_cast(half8, bq[st % NB][nb * 2]) * (_Float16)(1.0f / 2048.0f);
+        auto afrag = [&](int mb, int pl) -> half8 {
+          if constexpr (ROWREUSE) return ar[(mb + pos % 3) % 5][pl];
+          else return a[mb][pl];
+        };
+#define DMH_A(mb, pl) afrag(mb, pl)
 #define DMH_TERM(pl, bexpr)                                                                       \
   _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
       acc[mb][(st & 1) * 2 + nb] =                                                                \
-          __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][(st & 1) * 2 + nb], 0, 0, 0);
+          __builtin_amdgcn_mfma_f32_16x16x32_f16(DMH_A(mb, pl), bexpr, acc[mb][(st & 1) * 2 + nb], 0, 0, 0);
         DMH_TERM(1, g1s[nb])                                                 // h2 * g1s   (smallest terms first)
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2 + 1]))      // h1 * g2
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h1 * g1
 #undef DMH_TERM
-        ++step;
+#undef DMH_A
       }
     }
     __builtin_amdgcn_sched_barrier(0);
