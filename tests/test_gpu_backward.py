@@ -432,8 +432,11 @@ def test_train_step_follows_moved_parameter_storage(golden_dir):
         a, b = ts.step([(img, classes)], draws=[draws]), ts2.step([(img2, classes2)], draws=[draws2])
         assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)), (i, float(a), float(b))
     for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.isfinite(p.detach()).all(), k                                  # a stale read would be NaN
+        if k.endswith('.proj.bias'):
+            continue      # a conv bias in front of a GroupNorm: its true gradient is 0, Adam amplifies the rounding noise
         err = (p.detach() - q.detach()).abs().max().item()
-        assert err <= 2e-5 * max(1e-3, q.detach().abs().max().item()), (k, err)     # NaN (a stale read) fails this too
+        assert err <= 2e-5 * max(1e-3, q.detach().abs().max().item()), (k, err)
     # the sampling engine follows too
     x = draws['noise']
     o1 = m(x, draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(), cond_drop_prob=0.)
