@@ -181,6 +181,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cfg-mode', default='streams', choices=['batched', 'streams'])
     ap.add_argument('--stream-splits', type=int, default=1, help="row sub-batches per CFG pass in 'streams' mode")
+    ap.add_argument('--no-graph', action='store_true', help="launch every kernel from Python instead of replaying the "
+                    "HIP graph of the sampling loop (cfg.GaussianDiffusion.hip_graph)")
     ap.add_argument('--no-roofline', action='store_true', help='skip the extra untimed step that carries the HIP events')
     ap.add_argument('--variants', action='store_true',
                     help='also time the opt-in dedup_dropped_rows mode (3 extra steps) and report it under "variants"')
@@ -221,6 +223,7 @@ def main():
     diffusion = cfg.GaussianDiffusion(model, image_size=args.image_size, timesteps=1000,
                                       sampling_timesteps=args.s_step, loss_type='l1', objective='pred_x0').to(device)
     D.broadcast_module_(diffusion, src=0)
+    diffusion.hip_graph = not args.no_graph
     torch.manual_seed(99 + rank)                         # device Philox stream for the noise
 
     # ---- synthetic conditions of this rank's shard, resident in HBM
@@ -252,6 +255,7 @@ def main():
     # cond + null rows in one launch sequence (exclusive per-launch durations; same kernels, same shapes)
     log = None
     if not args.no_roofline and rank == 0:
+        diffusion.hip_graph = False                      # (per-launch HIP events need eager launches)
         model.cfg_mode = 'batched'
         step_local = lambda: diffusion.sample(classes, rgb_flow, flow, mask)   # no collective: rank 0 only
         step_local()
@@ -265,6 +269,7 @@ def main():
     # dropped rows (cfg.Unet.dedup_dropped_rows: identical outputs, B + kept rows per denoise step instead of 2B)
     dedup_elapsed = 0.0
     if args.variants:
+        diffusion.hip_graph = False                      # (the de-duplication reads its mask on the host every step)
         model.cfg_mode, model.dedup_dropped_rows = 'batched', True
         step()
         fence()
@@ -299,7 +304,7 @@ def main():
                                        (args.dim, args.image_size, args.bs, args.s_step) == (128, 256, 8, 250) else
                                        '(non-BASELINE configuration)'),
                        'global_batch': args.bs * world, 'sharding': f'samples x{world}, no data-path collective',
-                       'cfg_mode': args.cfg_mode,
+                       'cfg_mode': args.cfg_mode, 'hip_graph': not args.no_graph,
                        'weights': 'seeded random init', 'noise': 'device Philox',
                        'arithmetic': 'fp32 tensors; 3x3 / 1x1 convolutions and the attention projections multiply block-scaled '
                                      'fp16 pieces of the fp32 operands on the matrix cores (3 MFMAs per product block, '

@@ -187,11 +187,19 @@ class ScheduleHost:
     0-dim fp32 tensor arithmetic on them (CFG:697-701); here the same ops run on CPU copies and the results
     enter the sampler kernel as scalars."""
 
+    _HOST_NAMES = ('alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod', 'sqrt_alphas_cumprod',
+                   'sqrt_one_minus_alphas_cumprod', 'posterior_mean_coef1', 'posterior_mean_coef2',
+                   'posterior_log_variance_clipped')
+
     def _host(self):
-        return {n: getattr(self, n).detach().cpu() for n in
-                ('alphas_cumprod', 'sqrt_recip_alphas_cumprod', 'sqrt_recipm1_alphas_cumprod', 'sqrt_alphas_cumprod',
-                 'sqrt_one_minus_alphas_cumprod', 'posterior_mean_coef1', 'posterior_mean_coef2',
-                 'posterior_log_variance_clipped')}
+        """CPU copies of the schedule buffers, cached per buffer version (a device -> host copy per sampling call would
+        also be illegal inside a HIP-graph capture)."""
+        sig = tuple((getattr(self, n).data_ptr(), getattr(self, n)._version) for n in self._HOST_NAMES)
+        cache = self.__dict__.get('_host_cache')
+        if cache is None or cache[0] != sig:
+            cache = (sig, {n: getattr(self, n).detach().cpu() for n in self._HOST_NAMES})
+            self.__dict__['_host_cache'] = cache
+        return cache[1]
 
     def _ddim_coef(self, host, time, time_next):
         """sqrt(alpha_next), c, sigma in the reference's op order, CFG:697-701."""
@@ -298,6 +306,13 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                         '(CFG:656 vs CFG:719-720); use sampling_timesteps < timesteps (DDIM), or the unconditional '
                         'denoising_diffusion_pytorch.GaussianDiffusion for ancestral sampling')
 
+    # hip_graph = True: the whole S-step sampling loop of CFG:683-707 (every kernel of every denoise step, on however many
+    # HIP streams cfg_mode uses) is captured ONCE per (shapes, cond_scale, weight version) into a HIP graph and replayed:
+    # one host call per sample() instead of ~660 launches per denoise step from Python.  Same kernels, same order, same
+    # device RNG stream (the Philox offsets are graph inputs): results are bitwise those of the eager path.  Off by
+    # default (the first call pays an eager warm-up and the capture); bench.py switches it on.
+    hip_graph = False
+
     @torch.no_grad()
     def sample(self, classes, rgb_flow, flow, mask, cond_scale=3.):
         """CFG:713-720."""
@@ -305,8 +320,46 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         shape = (batch_size, channels, image_size, image_size)
         if not self.is_ddim_sampling:
             return self.p_sample_loop(classes, rgb_flow, flow, mask, shape, cond_scale)    # TypeError, as CFG:719-720
+        if self.hip_graph and type(self.rng) is DeviceRng:
+            return self._sample_graphed(classes, rgb_flow, flow, mask, shape, cond_scale)
         rgb_flow = ops.affine(rgb_flow.to(torch.float32), 2., -1.)      # normalize_to_neg_one_to_one, CFG:716
         return self.ddim_sample(classes, rgb_flow, flow, mask, shape, cond_scale)
+
+    def _sample_graphed(self, classes, rgb_flow, flow, mask, shape, cond_scale):
+        eng = self.model._engine
+        eng.ensure_prepared()
+        key = (tuple(shape), tuple(rgb_flow.shape), float(cond_scale), self.model.cfg_mode, int(self.model.stream_splits),
+               bool(self.model.dedup_dropped_rows), eng._sig, self.sampling_timesteps, self.objective,
+               str(classes.device))
+        st = self.__dict__.get('_graph_state')
+        if st is None or st['key'] != key:
+            if self.model.dedup_dropped_rows:
+                raise RuntimeError('hip_graph: dedup_dropped_rows reads the class-dropout mask on the host every step and '
+                                   'cannot be captured')
+            self._host()                                     # (host mirrors cached before the capture)
+            ins = [classes.clone(), rgb_flow.to(torch.float32).clone(), flow.clone(), mask.clone()]
+
+            def body():
+                rf = ops.affine(ins[1], 2., -1.)
+                img, _, _ = self.ddim_sample(ins[0], rf, ins[2], ins[3], shape, cond_scale)
+                return img
+            # eager warm-up on a side stream (first-launch work: LDS attributes, side streams, weight packs), as
+            # torch.cuda.graphs asks for; it draws from the RNG like any sample() call would
+            side = torch.cuda.Stream(device=classes.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                out = body()
+            st = {'key': key, 'graph': g, 'ins': ins, 'out': out}
+            self.__dict__['_graph_state'] = st
+        else:
+            for dst, src in zip(st['ins'], (classes, rgb_flow, flow, mask)):
+                dst.copy_(src)
+        st['graph'].replay()
+        return st['out'].clone(), mask, flow
 
     @torch.no_grad()
     def interpolate(self, x1, x2, t=None, lam=0.5):

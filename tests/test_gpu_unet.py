@@ -345,6 +345,37 @@ def test_sample_bs25_s32_rows_match_bs2():
     assert torch.equal(outs[25][:2], outs[2])
 
 
+@pytest.mark.parametrize('mode', ['batched', 'streams'])
+def test_sample_hip_graph_equals_eager(mode):
+    """GaussianDiffusion.hip_graph: the whole S-step sampling loop captured into one HIP graph (the hot
+    loop CFG:683-707) replays bitwise what the eager launch sequence computes from the same device RNG state — also when
+    the inputs change between replays, and again after a weight update (re-capture on the new weight version)."""
+    from dmhomo_amd import cfg
+    m, sd = make_cfg(8)
+    m.cfg_mode = mode
+    d = cfg.GaussianDiffusion(m, image_size=32, timesteps=1000, sampling_timesteps=6, objective='pred_x0').to(dev())
+    _, rf, mk = _cond_inputs(3, 32, 900)
+    rf01, flow, c = g((rf + 1) / 2), g(rand((3, 2, 32, 32), 903)), g(torch.zeros(3, dtype=torch.long))
+    mk = g(mk)
+
+    def run(graph, seed, rf_in):
+        d.hip_graph = graph
+        torch.manual_seed(seed)
+        img, mo, fo = d.sample(c, rf_in, flow, mk)
+        return img.clone()
+    eager5, eager6 = run(False, 5, rf01), run(False, 6, 1 - rf01)
+    run(True, 1, rf01)                                   # warm-up + capture (+ one replay)
+    assert torch.equal(run(True, 5, rf01), eager5)
+    assert torch.equal(run(True, 6, 1 - rf01), eager6)   # new inputs, new RNG state, same graph
+    assert d.__dict__['_graph_state']['graph'] is not None
+    with torch.no_grad():
+        m.final_conv.bias.add_(0.25)                     # a new weight version: re-capture, not a stale replay
+    e = run(False, 5, rf01)
+    assert not torch.equal(e, eager5)
+    assert torch.equal(run(True, 5, rf01), e)
+    d.hip_graph = False
+
+
 def test_exact_fp32_conv_variant_in_child_process():
     """DMH_CONV3_VARIANT=6 — the exact-fp32 Winograd 3x3 path the bench line advertises as the alternative to the
     fp16-piece kernel — is read once per process, so it is exercised in a fresh child: conv2d kernel parity and the
