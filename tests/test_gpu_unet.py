@@ -372,6 +372,9 @@ def test_sample_hip_graph_equals_eager(mode):
         m.final_conv.bias.add_(0.25)                     # a new weight version: re-capture, not a stale replay
     e = run(False, 5, rf01)
     assert not torch.equal(e, eager5)
+    g_old = d.__dict__['_graph_state']['graph']
+    run(True, 1, rf01)                                   # (the re-capture call warms up eagerly: it draws from the RNG)
+    assert d.__dict__['_graph_state']['graph'] is not g_old
     assert torch.equal(run(True, 5, rf01), e)
     d.hip_graph = False
 
