@@ -1,4 +1,4 @@
-"""profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
+"""profiles/r0N_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over bench.py.
 
     python tools/pmc_traffic.py <fetch_pass_dir> <write_pass_dir> <kernel substring> <out.json>
 Units / corrections as MI355X_MICROARCH.md §HBM prescribes: the counters are in KiB; on gfx950 FETCH_SIZE
@@ -19,6 +19,6 @@ out = {'kernel': sys.argv[3], 'launches': n1,
        'fetch_bytes_per_launch': 2 * fetch_kib * 1024, 'write_bytes_per_launch': write_kib * 1024,
        'hbm_bytes_per_launch': 2 * fetch_kib * 1024 + write_kib * 1024,
        'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --s_step 2 '
-               '--cfg-mode batched`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request)'}
+               '--cfg-mode batched --no-graph --no-roofline` (tools/profile_round.sh), averaged over the stride-1 3x3 launches; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 64 B per 128 B request)'}
 json.dump(out, open(sys.argv[4], 'w'), indent=1)
 print(out)
