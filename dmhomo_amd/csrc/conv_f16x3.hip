@@ -47,17 +47,6 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-// Wave priority (s_setprio) between the two waves that share a SIMD, measured same-box (round 2, B = 50): with the
-// matrix phase raised to priority 1 the 128-channel-wide workgroups (2 x 2 waves; deep layers, many chunks per tile) gain
-// 3-4 % (171 -> 165, 164 -> 156 us) — an MFMA stream that is never held up by the partner's staging instructions — and
-// the 64-channel ones at 128^2 (4 x 1 waves; two chunks per tile, staging-heavy) lose 3-4 % (235 -> 246 us).
-#ifndef DMH_PRIO_MATRIX_WIDE
-#define DMH_PRIO_MATRIX_WIDE 1
-#endif
-#ifndef DMH_PRIO_STAGE_NARROW
-#define DMH_PRIO_STAGE_NARROW 0
-#endif
-
 namespace {
 
 constexpr int KC = 32;                // input channels per chunk
@@ -339,8 +328,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     if (!(p.ablate & 2))
 #endif
     {
-      if (WN == 2) __builtin_amdgcn_s_setprio(DMH_PRIO_MATRIX_WIDE);
-      else if (DMH_PRIO_STAGE_NARROW) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int st = 0; st < NSTEP; ++st) {          // st = 2 * (position in the tap walk) + (half of the output channels)
 #ifdef DMH_STAMPS
@@ -381,8 +368,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #undef DMH_A
       }
     }
-    if (WN == 2) __builtin_amdgcn_s_setprio(0);
-    else if (DMH_PRIO_STAGE_NARROW) __builtin_amdgcn_s_setprio(DMH_PRIO_STAGE_NARROW);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4)  // matrix phase
   }
