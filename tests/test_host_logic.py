@@ -187,3 +187,35 @@ def test_trainer_split_batches_semantics():
     assert tr.batch_size == 6 and tr.rank_batch_size == 6 and tr.split_batches      # one process: the whole batch
     tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=6, split_batches=False)
     assert tr.rank_batch_size == 6
+
+
+def test_bench_roofline_is_a_fraction_of_the_pipe_that_runs():
+    """bench.py's `roofline` object from a synthetic HIP-event log: frac = achieved / peak with the peak of the pipe the
+    kernel executes on (2.5 PFLOP/s fp16 MFMA / 3 executed FLOPs per algorithmic one), never above 1 for a physically
+    possible time; the canonical launch's HBM-equivalent fraction; the sub-pixel convs kept out of frac"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Ev:
+        def __init__(self, ms=None):
+            self.ms = ms
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    class A:
+        bs, image_size = 25, 128
+    # (e0, e1, k, stride, B, ho, wo, cin, cout, ups): two canonical 3x3 launches at 190 us, one 1x1, one sub-pixel conv
+    log = [(Ev(), Ev(0.190), 3, 1, 50, 128, 128, 64, 64, 0), (Ev(), Ev(0.190), 3, 1, 50, 128, 128, 64, 64, 0),
+           (Ev(), Ev(0.100), 1, 1, 50, 128, 128, 128, 64, 0), (Ev(), Ev(0.165), 3, 1, 50, 128, 128, 128, 64, 2)]
+    r = bench.roofline(log, A)
+    flop = 2.0 * 9 * 64 * 64 * 128 * 128 * 50
+    assert r['launches'] == 2 and abs(r['achieved'] - flop / 0.190e-3 / 1e12) < 1e-6
+    assert abs(r['peak'] - 2500.0 / 3) < 1e-9 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] < 1
+    assert abs(r['executed']['frac'] - r['frac']) < 1e-12
+    assert abs(r['hbm_frac_canonical'] - 419604224.0 / 190e-6 / 8e12) < 1e-9
+    assert r['canonical_64to64_128sq']['launches'] == 2 and r['subpixel_upsample_convs']['TFLOP/s_algorithmic'] > 0
+    assert r['traffic'] is None or r['traffic_source'].startswith('profiles/')
