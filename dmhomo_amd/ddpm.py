@@ -182,11 +182,56 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         cb = self.sqrt_one_minus_alphas_cumprod.gather(-1, t).contiguous()
         return ops.q_sample(x_start.contiguous(), noise.contiguous(), ca, cb)
 
+    @property
+    def loss_fn(self):
+        """DDP:763-770 — the name of the elementwise loss (the reduction runs in dmh_diff_mean)."""
+        if self.loss_type in ('l1', 'l2'):
+            return self.loss_type
+        raise ValueError(f'invalid loss type {self.loss_type}')
+
+    _random = staticmethod(__import__('random').random)      # the `random() < 0.5` self-conditioning draw of DDP:785
+
+    @torch.no_grad()
     def p_losses(self, x_start, t, noise=None):
-        raise NotImplementedError('training (p_losses + backward kernels) is SURVEY.md §8f "next" row 1, not built yet')
+        """DDP:772-811, FORWARD VALUE: q_sample -> (self-conditioning pass, half of the time) -> UNet -> per-sample L1 / L2
+        mean -> x p2_loss_weight[t] -> mean.  The DGM trains the conditional class (classifier_free_guidance, built with
+        its backward in dmhomo_amd.train); this unconditional twin returns the loss value without an autograd graph."""
+        squared = self.loss_fn == 'l2'
+        x_start = x_start.to(torch.float32).contiguous()
+        noise = default(noise, lambda: self.rng.randn(x_start.shape, x_start.device)).to(torch.float32).contiguous()
+        t = t.to(torch.int64).contiguous()
+        x = self.q_sample(x_start, t, noise)
+        x_self_cond = None
+        if self.self_condition and self._random() < 0.5:
+            out0 = self.model(x, t, None)                    # model_predictions(x, t).pred_x_start, DDP:787 (no clamp)
+            if self.objective == 'pred_x0':
+                x_self_cond = out0
+            else:                                            # per-sample coefficients: t differs from row to row
+                ca = (self.sqrt_recip_alphas_cumprod if self.objective == 'pred_noise' else self.sqrt_alphas_cumprod)
+                cb = (self.sqrt_recipm1_alphas_cumprod if self.objective == 'pred_noise'
+                      else self.sqrt_one_minus_alphas_cumprod)
+                x_self_cond = ops.q_sample(x, out0.contiguous(), ca.gather(-1, t).contiguous(),
+                                           (-cb).gather(-1, t).contiguous())
+        model_out = self.model(x, t, x_self_cond)
+        if self.objective == 'pred_noise':
+            target = noise
+        elif self.objective == 'pred_x0':
+            target = x_start
+        elif self.objective == 'pred_v':                     # predict_v, DDP:596-598
+            target = ops.q_sample(noise, x_start, self.sqrt_alphas_cumprod.gather(-1, t).contiguous(),
+                                  (-self.sqrt_one_minus_alphas_cumprod).gather(-1, t).contiguous())
+        else:
+            raise ValueError(f'unknown objective {self.objective}')
+        loss = ops.diff_mean(model_out, target, None, squared)                         # (B,) per-sample means
+        w = self.p2_loss_weight.gather(-1, t).contiguous()
+        return ops.loss_combine(torch.zeros_like(loss), loss, w)                       # mean(loss * w), DDP:810-811
 
     def forward(self, img, *args, **kwargs):
-        raise NotImplementedError('training (GaussianDiffusion.forward -> p_losses) is SURVEY.md §8f "next" row 1')
+        """DDP:813-820."""
+        b, c, h, w = img.shape
+        assert h == self.image_size and w == self.image_size, f'height and width of image must be {self.image_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
+        return self.p_losses(ops.affine(img.to(torch.float32), 2., -1.), t, *args, **kwargs)
 
 
 # =====================================================================================

@@ -312,6 +312,36 @@ def q_sample(buf, x_start, t, noise):
             extract(buf['sqrt_one_minus_alphas_cumprod'], t, nd) * noise)
 
 
+def ddp_p_losses(sd, buf, x_start, t, noise, *, objective='pred_noise', loss_type='l1', self_condition=False,
+                 use_self_cond=False, groups=8):
+    """DDP GaussianDiffusion.p_losses, DDP:772-811 (forward value).  ``use_self_cond`` is the outcome of the reference's
+    ``random() < 0.5`` draw (DDP:785): when set (and the model is self-conditioned) the network first predicts x_start
+    without a self-condition (model_predictions, DDP:787, no clamp) and is then run again conditioned on it."""
+    import torch.nn.functional as F
+    x = q_sample(buf, x_start, t, noise)
+    x_self_cond = None
+    if self_condition and use_self_cond:
+        out0 = _ddp_model(sd, x, t, None, self_condition, groups)
+        _, x_self_cond = _predictions(buf, objective, out0, x, t, False)
+    model_out = _ddp_model(sd, x, t, x_self_cond, self_condition, groups)
+    if objective == 'pred_noise':
+        target = noise
+    elif objective == 'pred_x0':
+        target = x_start
+    elif objective == 'pred_v':
+        nd = x_start.dim()
+        target = (extract(buf['sqrt_alphas_cumprod'], t, nd) * noise -
+                  extract(buf['sqrt_one_minus_alphas_cumprod'], t, nd) * x_start)       # predict_v, DDP:596-598
+    else:
+        raise ValueError(f'unknown objective {objective}')
+    loss = (F.l1_loss if loss_type == 'l1' else F.mse_loss)(model_out, target, reduction='none')
+    # einops' reduce(loss, 'b ... -> b (...)', 'mean') reduces nothing (it only flattens, DDP:808): every element is
+    # weighted by its sample's p2 weight and ONE mean runs over all of them (DDP:810-811)
+    loss = loss.reshape(loss.shape[0], -1)
+    loss = loss * extract(buf['p2_loss_weight'], t, loss.dim())
+    return loss.mean()
+
+
 def cfg_p_losses(sd, buf, x_start, t, classes, rgb_flow, flow, mask, noise, keep_mask, *, objective='pred_x0',
                  loss_type='l1', groups=8):
     """CFG GaussianDiffusion.p_losses, CFG:770-806 (forward value only).  ``keep_mask`` is the class-dropout

@@ -465,6 +465,27 @@ def test_unet_ddp_fullsize_vs_oracle():
     close_rel('ddp full', m(g(x), g(t), g(xs)).cpu(), ref, OUT_REL)
 
 
+@pytest.mark.parametrize('tag', ['nosc', 'sc'])
+def test_ddp_p_losses_forward_vs_golden(golden_dir, tag):
+    """D9 for the unconditional class (DDP:772-820): the reference's own p_losses value for three objective / loss /
+    p2-weight combinations and both outcomes of the self-conditioning draw (per-sample timesteps)"""
+    from dmhomo_amd import ddpm
+    gd = load(golden_dir, 'ddp_train_forward')
+    sc = tag == 'sc'
+    m, sd = make_ddp(8, sc)
+    for obj, lt, gamma in (('pred_noise', 'l1', 0.), ('pred_x0', 'l2', 0.5), ('pred_v', 'l1', 1.0)):
+        d = ddpm.GaussianDiffusion(m, image_size=16, timesteps=1000, objective=obj, loss_type=lt,
+                                   p2_loss_weight_gamma=gamma).to(dev())
+        for use in ((0, 1) if sc else (0,)):
+            d._random = (lambda: 0.1) if use else (lambda: 0.9)
+            loss = d.p_losses(g(T(gd['x_start'])), g(T(gd['t'])), noise=g(T(gd['noise'])))
+            want = float(gd[f'{tag}.{obj}.{lt}.use{use}'])
+            print(f'[parity] ddp p_losses {tag} {obj}/{lt} use_self_cond={use}: got {float(loss):.7f} want {want:.7f}')
+            assert abs(float(loss) - want) <= 2e-5 * max(1.0, abs(want))
+    val = d(g((T(gd['x_start']) + 1) / 2))                       # forward: normalise, random t (device RNG)
+    assert val.ndim == 0 and bool(torch.isfinite(val))
+
+
 def test_ddp_interpolate_vs_golden(golden_dir):
     """D10, DDP:737-754 against the reference: t = 0 is the reference's interpolate as it stands; t = 3 is the
     reference's own q_sample / p_sample in the chain the method means (it raises for t > 0: see oracle.diffusion.

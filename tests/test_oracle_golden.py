@@ -224,6 +224,22 @@ def test_train_forward(golden_dir, meta, obj, lt):
     close(loss, g[f'{obj}.{lt}.loss'], rtol=1e-5, atol=1e-6)
 
 
+# ------------------------------------------------------------------------- D9, unconditional twin
+@pytest.mark.parametrize('tag', ['nosc', 'sc'])
+def test_ddp_train_forward(golden_dir, meta, tag):
+    """DDP:772-811 p_losses forward value incl. p2 loss weights and both outcomes of the self-conditioning draw"""
+    g = load(golden_dir, 'ddp_train_forward')
+    sc = tag == 'sc'
+    sd = sd_from(meta, f'unet_ddp_tiny_{tag}', seed=1)
+    for obj, lt, gamma in (('pred_noise', 'l1', 0.), ('pred_x0', 'l2', 0.5), ('pred_v', 'l1', 1.0)):
+        buf = OD.schedule_buffers(1000, 'cosine', p2_loss_weight_gamma=gamma)
+        for use in ((0, 1) if sc else (0,)):
+            with torch.no_grad():
+                loss = OD.ddp_p_losses(sd, buf, T(g['x_start']), T(g['t']), T(g['noise']), objective=obj, loss_type=lt,
+                                       self_condition=sc, use_self_cond=bool(use))
+            close(loss, g[f'{tag}.{obj}.{lt}.use{use}'], rtol=1e-5, atol=1e-6)
+
+
 # ------------------------------------------------------------------------- F6
 @pytest.mark.parametrize('tag', ['nosc', 'sc'])
 def test_ddpm_trace(golden_dir, meta, tag):
