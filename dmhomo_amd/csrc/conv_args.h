@@ -112,36 +112,62 @@ struct EpilogueRows {
   }
 
   // same, the 32 rows x this lane's channel quad coming from fetch(rr) instead of a plain slab
+  // The residual rows of all 8 row groups of a 32-row pass are requested FIRST, unconditionally and from clamped addresses,
+  // so that they are in flight together: loaded one by one inside the guarded loop (round 1) each of them exposed a full
+  // memory round trip; the 128->64 @128^2 res_conv took 240 us with this epilogue against 140 us without a residual
+  // (round 2: 190 us in isolation; in the two-stream step the stall was already covered by the other stream's kernels —
+  // no change of images/s.  Requesting the rows ahead of the LDS transposition as well cost the launches WITHOUT a
+  // residual 4 % and gained nothing: not kept).
+  size_t oo[8];
+  bool okr[8];
+  float4 rv[8];
+  bool pre = false;
+  template <int TW>
+  __device__ __forceinline__ void prefetch_rows(const ConvArgs& p, int row_base, int oy0, int ox0, int mul = 1, int dy = 0,
+                                                int dx = 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row_base + i * 4 + rsub;
+      const int oy = (oy0 + row / TW) * mul + dy, ox = (ox0 + row % TW) * mul + dx;
+      okr[i] = cok && oy < p.Hout && ox < p.Wout;
+      const int oyc = min(oy, p.Hout - 1), oxc = min(ox, p.Wout - 1);
+      oo[i] = ((size_t)(b * p.Hout + oyc) * p.Wout + oxc) * p.Cout + (cok ? chn : 0);
+    }
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rv[i] = ld4(p.res + oo[i]);
+    }
+    pre = true;
+  }
+
   template <int TW, typename Fetch>
   __device__ __forceinline__ void store_rows_fn(const ConvArgs& p, Fetch fetch, int row_base, int oy0, int ox0,
                                                 int mul = 1, int dy = 0, int dx = 0) {
+    if (!pre) prefetch_rows<TW>(p, row_base, oy0, ox0, mul, dy, dx);
+    pre = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rr = i * 4 + rsub;
-      const int row = row_base + rr;
-      const int oy = (oy0 + row / TW) * mul + dy, ox = (ox0 + row % TW) * mul + dx;
-      if (cok && oy < p.Hout && ox < p.Wout) {
+      if (okr[i]) {
         float4 val = fetch(rr);
-        const size_t o = ((size_t)(b * p.Hout + oy) * p.Wout + ox) * p.Cout + chn;
         val.x = fmaf(val.x, osc.x, bias.x);  // osc == 1 unless the kernel scaled its weights: then exactly val + bias
         val.y = fmaf(val.y, osc.y, bias.y);
         val.z = fmaf(val.z, osc.z, bias.z);
         val.w = fmaf(val.w, osc.w, bias.w);
         if (p.res) {
-          const float4 rv = ld4(p.res + o);
           if (p.res_coef) {
-            val.x += silu_fast(fmaf(ra.x, rv.x, rb.x));
-            val.y += silu_fast(fmaf(ra.y, rv.y, rb.y));
-            val.z += silu_fast(fmaf(ra.z, rv.z, rb.z));
-            val.w += silu_fast(fmaf(ra.w, rv.w, rb.w));
+            val.x += silu_fast(fmaf(ra.x, rv[i].x, rb.x));
+            val.y += silu_fast(fmaf(ra.y, rv[i].y, rb.y));
+            val.z += silu_fast(fmaf(ra.z, rv[i].z, rb.z));
+            val.w += silu_fast(fmaf(ra.w, rv[i].w, rb.w));
           } else {
-            val.x += rv.x;
-            val.y += rv.y;
-            val.z += rv.z;
-            val.w += rv.w;
+            val.x += rv[i].x;
+            val.y += rv[i].y;
+            val.z += rv[i].z;
+            val.w += rv[i].w;
           }
         }
-        st4(p.out + o, val);
+        st4(p.out + oo[i], val);
         s1.x += val.x;
         s1.y += val.y;
         s1.z += val.z;

@@ -20,6 +20,8 @@ SHAPES = [  # name, B, H, W, C0, C1, Cout, k, stride, ups, prologue
     ('1x1_64_384_128', 50, 128, 128, 64, 0, 384, 1, 1, 0, 0),
     ('1x1_128_64_128', 50, 128, 128, 128, 0, 64, 1, 1, 0, 0),
     ('1x1_64+64_64_128', 50, 128, 128, 64, 64, 64, 1, 1, 0, 0),
+    ('1x1_64+64_64_128_gnres', 50, 128, 128, 64, 64, 64, 1, 1, 0, 2),   # prologue field 2: + SiLU(a*res+b) residual epilogue
+    ('1x1_128_512_16_res', 50, 16, 16, 128, 0, 512, 1, 1, 0, 3),        # 3: + plain residual (attention to_out)
     ('1x1_128_384_64', 50, 64, 64, 128, 0, 384, 1, 1, 0, 0),
     ('1x1_512_384_16', 50, 16, 16, 512, 0, 384, 1, 1, 0, 0),
     ('7x7_12_64_128', 50, 128, 128, 12, 0, 64, 7, 1, 0, 0),
@@ -51,15 +53,20 @@ def main():
             if s1 is not None:
                 s1.zero_()
         coef = None
-        if pro:
+        res = rcoef = None
+        if pro >= 2:
+            res = torch.randn((B, H, W, Cout), device=dev)
+            if pro == 2:
+                rcoef = torch.stack([1 + 0.1 * torch.randn(B, Cout, device=dev), 0.1 * torch.randn(B, Cout, device=dev)], 1).contiguous()
+        if pro == 1:
             coef = torch.stack([1 + 0.1 * torch.randn(B, C0, device=dev), 0.1 * torch.randn(B, C0, device=dev)], 1).contiguous()
         for _ in range(3):
-            out = ops.conv2d(pc, s0, s1, in_coef=coef, want_stats=(k == 3 and pc.upsample2 != 2))
+            out = ops.conv2d(pc, s0, s1, in_coef=coef, res=res, res_coef=rcoef, want_stats=(k == 3 and pc.upsample2 != 2))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(args.reps):
-            out = ops.conv2d(pc, s0, s1, in_coef=coef, want_stats=(k == 3 and pc.upsample2 != 2))
+            out = ops.conv2d(pc, s0, s1, in_coef=coef, res=res, res_coef=rcoef, want_stats=(k == 3 and pc.upsample2 != 2))
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / args.reps * 1e3
