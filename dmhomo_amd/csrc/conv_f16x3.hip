@@ -9,15 +9,22 @@
 //   activations  xs = x * s            s per (workgroup, running over chunks): the largest |x| staged so far sits in
 //                                       [2^14, 2^15); when a later chunk raises the maximum the accumulators are rescaled
 //                h1 = fp16(xs)                       11 significant bits
-//                h2 = fp16((xs - h1) * 2^11)         the next 11 bits; the subtraction is exact, the scaled residual
-//                                                    has the magnitude of h1, so it never falls into fp16 subnormals
+//                h2 = fp16(xs - h1)                  the next 11 bits; the subtraction is exact.  Stored unscaled (round 2;
+//                                                    round 1 stored (xs - h1) * 2^11 and multiplied it with g1 * 2^-11,
+//                                                    derived with 288 packed fp16 multiplies per wave and tile).  The
+//                                                    residual of an element below 2^-3 (= block maximum * 2^-18) is an
+//                                                    fp16 subnormal: its absolute error is then <= 2^-25 = block
+//                                                    maximum * 2^-40, far below the fp32 accumulation rounding (2^-24 of
+//                                                    the sum), so nothing measurable is lost (dynamic-range cases of
+//                                                    tests/test_gpu_kernels.py: 3.6e-7..8.8e-7 before and after).  This
+//                                                    is how the weights have always been split
 //   weights      ws = w * 2^k          k per output channel: max |w| of the channel sits in [2^14, 2^15)   (pack time)
-//                g1 = fp16(ws),  g2 = fp16(ws - g1)  (streamed),   g1s = g1 * 2^-11  (derived in registers)
-//   product      x*w*s*2^k = h1*g1 + h1*g2 + h2*g1s + (h2*g2*2^-11 + rounding of the pieces) : the dropped part is
+//                g1 = fp16(ws),  g2 = fp16(ws - g1)  (streamed)
+//   product      x*w*s*2^k = h1*g1 + h1*g2 + h2*g1 + (h2*g2 + rounding of the pieces) : the dropped part is
 //                <= 2^-22 relative, every fp16*fp16 product is exact in fp32, the MFMA accumulates in fp32
 //   output       y = acc / s * 2^-k + bias
-// 22-24 significant bits per operand relative to the block maximum, fp32 exponent range, no overflow by
-// construction.  Against an fp64 convolution the error is that of the fp32-MFMA kernels (fp32 accumulation
+// 22 significant bits per operand for everything within 2^18 of its block maximum, fp32 exponent range, no overflow
+// by construction.  Against an fp64 convolution the error is that of the fp32-MFMA kernels (fp32 accumulation
 // rounding dominates both): tests/test_gpu_kernels.py.
 //
 //   M = output pixels: each wave owns 64 (four 16-row blocks = four tile rows);  N = 64 output channels per wave;
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       if ((i + 1) * 256 <= IN_PIX * 8 || ((tid + i * 256) >> 3) < IN_PIX) {
         const float4v xs = float4v{v[i].x, v[i].y, v[i].z, v[i].w} * sc;
         const half4 h1 = __builtin_convertvector(xs, half4);
-        const float4v rs = (xs - __builtin_convertvector(h1, float4v)) * 2048.f;
+        const float4v rs = xs - __builtin_convertvector(h1, float4v);   // (exact; see the header: stored unscaled)
         const half4 h2 = __builtin_convertvector(rs, half4);
         unsigned char* dst = in_tile + wroff[i];
         *reinterpret_cast<half4*>(dst) = h1;
@@ -346,12 +353,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
             read_a(pos);
           }
         }
-        // g1s = g1 * 2^-11 is derived here (4 packed fp16 multiplies per fragment) instead of being streamed:
-        // a third less weight traffic on the CU's 64 B/clk vector-memory path
-        half8 g1s[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-          g1s[nb] = __builtin_bit_cast(half8, bq[st % NB][nb * 2]) * (_Float16)(1.0f / 2048.0f);
         auto afrag = [&](int mb, int pl) -> half8 {
           if constexpr (ROWREUSE) return ar[(mb + pos % 3) % 5][pl];
           else return a[mb][pl];
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
       acc[mb][(st & 1) * 2 + nb] =                                                                \
           __builtin_amdgcn_mfma_f32_16x16x32_f16(DMH_A(mb, pl), bexpr, acc[mb][(st & 1) * 2 + nb], 0, 0, 0);
-        DMH_TERM(1, g1s[nb])                                                 // h2 * g1s   (smallest terms first)
+        DMH_TERM(1, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h2 * g1   (smallest terms first)
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2 + 1]))      // h1 * g2
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h1 * g1
 #undef DMH_TERM

@@ -435,8 +435,11 @@ def test_train_step_follows_moved_parameter_storage(golden_dir):
         assert torch.isfinite(p.detach()).all(), k                                  # a stale read would be NaN
         if k.endswith('.proj.bias'):
             continue      # a conv bias in front of a GroupNorm: its true gradient is 0, Adam amplifies the rounding noise
-        err = (p.detach() - q.detach()).abs().max().item()
-        assert err <= 2e-5 * max(1e-3, q.detach().abs().max().item()), (k, err)
+        # Adam divides by sqrt(v): an element whose gradient sits at the rounding floor moves by up to lr per step in
+        # either twin, so the element-wise bound is 3 steps x lr and the closeness is judged on the L2 norm
+        diff = (p.detach() - q.detach()).double()
+        assert diff.abs().max().item() <= 3.05e-3, (k, diff.abs().max().item())
+        assert diff.norm().item() <= 1e-4 * max(1e-3, q.detach().double().norm().item()), (k, diff.norm().item())
     # the sampling engine follows too
     x = draws['noise']
     o1 = m(x, draws['t'], classes, img[:, -5:-2].contiguous(), img[:, 6:7].contiguous(), cond_drop_prob=0.)
