@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     arow[mb] = UPS == 3 ? (mb + (wm >> 1)) * ROWP + (l15 + (wm & 1)) * PITCH + kg * 16
                         : ((wm * 4 + mb) * S) * ROWP + (l15 * S) * PITCH + kg * 16;
 
-  // accumulators: 4 row blocks x 4 column blocks of 16x16 (C/D layout: row = 4 * (lane >> 4) + r, col = lane & 15)
+  // accumulators: 4 pixel blocks x 4 channel blocks of 16x16.  The MFMA takes the WEIGHT fragment as its first operand, so
+  // D = W * X^T: row 4 * (lane >> 4) + r = output channel, column lane & 15 = pixel — a lane holds 4 consecutive channels
+  // of one pixel and the epilogue moves them as one 16 B piece
   float4v acc[4][4];
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb)
@@ -209,32 +211,44 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     inside |= (ok ? 1u : 0u) << i;
   }
   unsigned inside_ch = inside;  // validity mask of the chunk whose loads are in flight (UPS == 2: depends on the parity)
-  auto issue_chunk_loads = [&](int ch) {
+  // load i of chunk ch's tile (issue_prep(ch) first: it resolves the chunk's source and channel offset)
+  const float* ld_src = p.src0;
+  int ld_C = p.C0, ld_c = 0, ld_py = 0, ld_px = 0;
+  auto issue_prep = [&](int ch) {
     const bool s1 = ch >= p.nch0;
-    const float* src = s1 ? p.src1 : p.src0;
-    const int Csrc = s1 ? p.C1 : p.C0;
-    const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
-    const int cc = c < Csrc ? c : 0;
+    ld_src = s1 ? p.src1 : p.src0;
+    ld_C = s1 ? p.C1 : p.C0;
     if (UPS == 2) {
       // chunk = (pixel parity, 32 channels): source pixel (2*cy - 1 + py, 2*cx - 1 + px) of coarse cell (cy, cx)
       const int nchc = p.C0 / KC, par = ch / nchc;
-      const int py = par >> 1, px = par & 1;
-      const int c2 = (ch - par * nchc) * KC + c4 * 4;
+      ld_py = par >> 1;
+      ld_px = par & 1;
+      ld_c = (ch - par * nchc) * KC + c4 * 4;
       inside_ch = 0u;
-#pragma unroll
-      for (int i = 0; i < NLOAD; ++i) {
-        const int ry = 2 * (poff[i] >> 16) - 1 + py, rx = 2 * (poff[i] & 0xffff) - 1 + px;
-        const bool ok = ((inside >> i) & 1u) && ry >= 0 && ry < p.Hin && rx >= 0 && rx < p.Win;
-        const int yc = min(max(ry, 0), p.Hin - 1), xc = min(max(rx, 0), p.Win - 1);
-        v[i] = ld4(src + ((size_t)(b * p.Hin + yc) * p.Win + xc) * Csrc + c2);
-        inside_ch |= (ok ? 1u : 0u) << i;
-      }
-      return;
+    } else {
+      const int c = (s1 ? ch - p.nch0 : ch) * KC + c4 * 4;
+      ld_c = c < ld_C ? c : 0;
     }
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) v[i] = ld4(src + (size_t)poff[i] * Csrc + cc);
   };
-  issue_chunk_loads(0);
+  auto issue_one = [&](int i) {
+    const float* a;
+    if (UPS == 2) {
+      const int ry = 2 * (poff[i] >> 16) - 1 + ld_py, rx = 2 * (poff[i] & 0xffff) - 1 + ld_px;
+      const bool ok = ((inside >> i) & 1u) && ry >= 0 && ry < p.Hin && rx >= 0 && rx < p.Win;
+      const int yc = min(max(ry, 0), p.Hin - 1), xc = min(max(rx, 0), p.Win - 1);
+      a = ld_src + ((size_t)(b * p.Hin + yc) * p.Win + xc) * ld_C + ld_c;
+      inside_ch |= (ok ? 1u : 0u) << i;
+    } else {
+      a = ld_src + (size_t)poff[i] * ld_C + ld_c;
+    }
+#ifdef DMH_STAMPS
+    a = (p.ablate & 32) ? ld_src + ld_c : a;        // ablation: the tile loads hit one cached line (latency / HBM share)
+#endif
+    v[i] = ld4(a);
+  };
+  issue_prep(0);
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) issue_one(i);
   __syncthreads();                              // block-maximum slots are zeroed
 
   int e_run = 16;  // biased exponent of the running block maximum (clamped to [16, 254]); uniform
@@ -289,9 +303,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mb][nb] *= f;
     }
-    // ---- split into two fp16 planes -> LDS
+    // ---- split into two fp16 planes -> LDS.  v[i] is free once it is split, and the next chunk's load i is issued right
+    // there: a wave's loads return in order, so the weight fragments fetched after the tile loads wait for them too, and
+    // issued at the head of the matrix phase (round 1) the HBM latency of the tile stalled the third weight step of every
+    // chunk (64->64 @128^2: the matrix phase with a tile in flight took 16.7 k cycles, the one without 11.4 k)
+    const bool more = ch + 1 < nchunks;
+    if (more) issue_prep(ch + 1);
 #ifdef DMH_STAMPS
-    if (!(p.ablate & 1))
+    if (p.ablate & 1) {                             // ablation: no split / LDS write
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i)
+        if (more) issue_one(i);
+    } else
 #endif
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
@@ -304,12 +327,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
         *reinterpret_cast<half4*>(dst) = h1;
         *reinterpret_cast<half4*>(dst + 64) = h2;
       }
+      if (more) issue_one(i);
     }
     STAMP(2)  // rescale + split + LDS write
     __syncthreads();
     STAMP(3)  // barrier 2
-    // the next chunk's tile travels during this chunk's matrix phase (last chunk: harmless re-load of itself)
-    issue_chunk_loads(ch + 1 < nchunks ? ch + 1 : ch);
     __builtin_amdgcn_sched_barrier(0);
 
     // A fragments [row block][plane] of one tap (all 32 channels of the chunk: K = 32 per MFMA)
@@ -361,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #define DMH_TERM(pl, bexpr)                                                                       \
   _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
       acc[mb][(st & 1) * 2 + nb] =                                                                \
-          __builtin_amdgcn_mfma_f32_16x16x32_f16(DMH_A(mb, pl), bexpr, acc[mb][(st & 1) * 2 + nb], 0, 0, 0);
+          __builtin_amdgcn_mfma_f32_16x16x32_f16(bexpr, DMH_A(mb, pl), acc[mb][(st & 1) * 2 + nb], 0, 0, 0);
         DMH_TERM(1, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h2 * g1   (smallest terms first)
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2 + 1]))      // h1 * g2
         DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h1 * g1
@@ -383,17 +405,22 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     float* wl = lds + wave * (32 * EP);
     EpilogueRows er(p, b, n0);
     if (UPS == 3 && p.oscale) er.osc = ld4(p.oscale + nt * 64 + er.c4 * 4);  // the weight scale of the VIRTUAL channel
+    er.osc.x *= inv_s;                // 1 / (block scale) rides on the per-channel 2^-k: both powers of two
+    er.osc.y *= inv_s;
+    er.osc.z *= inv_s;
+    er.osc.w *= inv_s;
+    __syncthreads();                  // every wave is done reading the input tile, which the slabs overlay
 #pragma unroll
-    for (int hb = 0; hb < 2; ++hb) {  // two passes of 32 pixel rows through the wave's slab
-      __syncthreads();
+    for (int hb = 0; hb < 2; ++hb) {  // two passes of 32 pixel rows through the wave's OWN slab: a wave's LDS operations
+                                      // execute in order, so nothing but the wave itself has to be waited for
 #pragma unroll
       for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            wl[(m2 * 16 + kg * 4 + r) * EP + nb * 16 + l15] = acc[hb * 2 + m2][nb][r] * inv_s;
-      __syncthreads();
+          *reinterpret_cast<float4v*>(wl + (m2 * 16 + l15) * EP + nb * 16 + kg * 4) = acc[hb * 2 + m2][nb];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (UPS == 3) er.template store_rows<TW>(p, wl, hb * 32, oy0, ox0, 2, wm >> 1, wm & 1);
       else er.template store_rows<TW>(p, wl, wm * 64 + hb * 32, oy0, ox0);
     }

@@ -2,7 +2,8 @@
 time each phase accounts for.  Results are wrong by construction; only the times matter.
     python tools/f16_ablate.py
 ablate bits (DMH_WINO_ABLATE, read per launch by the stamps build): 1 no split / LDS write, 2 no matrix phase,
-4 no epilogue, 8 weight fragments loaded once (no B stream), 16 A fragments read once per chunk (no LDS reads)"""
+4 no epilogue, 8 weight fragments loaded once (no B stream), 16 A fragments read once per chunk (no LDS reads),
+32 the halo prefetch of chunks >= 1 reads one cached line, 64 no halo prefetch of chunks >= 1"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +13,7 @@ import torch
 from dmhomo_amd import ops
 
 dev = torch.device('cuda', 0)
-CASES = ((0, 'full'), (8, 'no B stream'), (16, 'no A reads'), (24, 'no B stream, no A reads'), (2, 'no matrix phase'),
+CASES = ((0, 'full'), (32, 'halo prefetch from one cached line'), (64, 'no halo prefetch'), (8, 'no B stream'), (16, 'no A reads'), (24, 'no B stream, no A reads'), (2, 'no matrix phase'),
          (1, 'no split / LDS write'), (4, 'no epilogue'), (6, 'no matrix, no epilogue'), (7, 'loads + prologue only'),
          (28, 'MFMA + staging only (no B, no A, no epilogue)'))
 for (C0, Cout, H, pro) in ((64, 64, 128, 1), (128, 128, 64, 1), (512, 512, 16, 1)):
