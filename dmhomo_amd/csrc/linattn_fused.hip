@@ -33,8 +33,16 @@ constexpr int TILE_BYTES = TP * PITCH;
 
 __device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
 
-// Stages one 32-channel chunk of a 64-pixel sub-tile: global x -> LayerNorm -> block scale -> two fp16 planes in LDS,
-// and keeps the running block scale of the sub-tile.  All 256 threads; thread = (pixel tid>>3 (+32), channel quad tid&7).
+// Stages one 32-channel chunk of a 64-pixel sub-tile: global x -> LayerNorm -> block scale -> two fp16 planes in LDS.
+// All 256 threads; thread = (pixel tid>>3 (+32), channel quad tid&7).
+//
+// The block scale is STATIC (round 2): |(x - mean) * rstd| <= sqrt(C - 1) for any C numbers, so sqrt(C) * max|g| bounds
+// every staged value, and with the second piece stored unscaled (conv_f16x3.hip) an over-estimated scale costs nothing
+// until it is 2^18 too large — so there is no block maximum to find: no reduction, no LDS atomic, no barrier in front of the
+// split, no accumulator rescale between chunks.  NBUF == 2 alternates two LDS tiles, which leaves ONE barrier per chunk
+// (tile written -> tile read; a wave writes tile q + 2 only after the barrier of q + 1, which every wave passes after its
+// reads of q); NBUF == 1 (the fully fused pass 2, whose LDS is taken by the head-exchange buffer) keeps the second one.
+template <int NBUF>
 struct Stager {
   const float* xb;     // x of this sample
   const float* g;      // LayerNorm gain
@@ -44,12 +52,22 @@ struct Stager {
   bool ok[2];
   float4 v[2];
   float4 gq;
-  int e_run;
-  int seq = 0;  // staged chunks so far (selects the block-maximum slot; keeps alternating across sub-tiles)
+  float sc, inv_sc;
+  int seq = 0;  // staged chunks so far (selects the LDS tile; keeps alternating across sub-tiles)
 
+  // every wave derives the same scale from g: bound = sqrt(C) * max|g|, bound * sc in [2^14, 2^15)
+  __device__ __forceinline__ void init_scale() {
+    float m = 0.f;
+    for (int i = threadIdx.x & 63; i < C; i += 64) m = fmaxf(m, fabsf(g[i]));
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const float bound = m * sqrtf((float)C);
+    const int e = min(max((int)(__builtin_amdgcn_readfirstlane(__float_as_uint(bound)) >> 23) & 0xff, 16), 254);
+    sc = __uint_as_float((unsigned)(268 - e) << 23);
+    inv_sc = __uint_as_float((unsigned)(e - 14) << 23);
+  }
   __device__ __forceinline__ void begin_tile(const float* stats_b, int p0_) {
     p0 = p0_;
-    e_run = 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pix = p0 + pix0 + 32 * i;
@@ -68,9 +86,11 @@ struct Stager {
     }
     gq = ld4(g + ch * KC + c4 * 4);
   }
-  // returns the factor (<= 1) the accumulators of the sub-tile must be multiplied with (1 when the scale is unchanged)
-  __device__ __forceinline__ float stage(unsigned char* tile, unsigned* mxslot, int ch) {
-    unsigned mx = 0u;
+  // returns the LDS tile the chunk was staged into
+  __device__ __forceinline__ unsigned char* stage(unsigned char* tiles) {
+    unsigned char* tile = tiles + (NBUF == 2 ? (seq & 1) * TILE_BYTES : 0);
+    ++seq;
+    if (NBUF == 1) __syncthreads();  // every wave is done reading the previous chunk's tile
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float4 x = v[i];
@@ -82,39 +102,18 @@ struct Stager {
       } else {
         x = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      v[i] = x;
-      mx = max(max(mx, absbits(x.x)), max(max(absbits(x.y), absbits(x.z)), absbits(x.w)));
-    }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
-    if ((threadIdx.x & 63) == 0) atomicMax(&mxslot[seq & 1], mx);
-    __syncthreads();  // block maximum complete; every wave is done reading the previous chunk's tile
-    const unsigned bmx = mxslot[seq & 1];
-    if (threadIdx.x == 0) mxslot[(seq + 1) & 1] = 0u;
-    ++seq;
-    const int e_old = e_run;
-    const int e_ch = min(max((int)(__builtin_amdgcn_readfirstlane(bmx) >> 23), 16), 254);
-    e_run = max(e_run, e_ch);
-    const float sc = __uint_as_float((unsigned)(268 - e_run) << 23);  // largest |x| * sc in [2^14, 2^15)
-    float f = 1.f;
-    if (e_run != e_old && ch > 0) {
-      const int fe = 127 + e_old - e_run;
-      f = fe > 0 ? __uint_as_float((unsigned)fe << 23) : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float4v xs = float4v{v[i].x, v[i].y, v[i].z, v[i].w} * sc;
+      const float4v xs = float4v{x.x, x.y, x.z, x.w} * sc;
       const half4 h1 = __builtin_convertvector(xs, half4);
-      const float4v rs = (xs - __builtin_convertvector(h1, float4v)) * 2048.f;
+      const float4v rs = xs - __builtin_convertvector(h1, float4v);   // exact; stored unscaled (conv_f16x3.hip)
       const half4 h2 = __builtin_convertvector(rs, half4);
       unsigned char* dst = tile + (pix0 + 32 * i) * PITCH + c4 * 8;
       *reinterpret_cast<half4*>(dst) = h1;
       *reinterpret_cast<half4*>(dst + 64) = h2;
     }
     __syncthreads();
-    return f;
+    return tile;
   }
-  __device__ __forceinline__ float inv_scale() const { return __uint_as_float((unsigned)(e_run - 14) << 23); }
+  __device__ __forceinline__ float inv_scale() const { return inv_sc; }
 };
 
 }  // namespace
@@ -127,24 +126,22 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
                                                             const float* __restrict__ oscale, float* __restrict__ partial,
                                                             int n, int C, int nsplit, int tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tile = smem;
-  unsigned* mxslot = reinterpret_cast<unsigned*>(smem + TILE_BYTES);
+  unsigned char* tiles_lds = smem;  // two staging tiles
 
   const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
   const int nch = C / KC;
 
-  Stager st;
+  Stager<2> st;
   st.xb = x + (size_t)b * n * C;
   st.g = g;
   st.C = C;
   st.n = n;
   st.c4 = tid & 7;
   st.pix0 = tid >> 3;
+  st.init_scale();
   const float* stats_b = stats + (size_t)b * n * 2;
-  if (tid < 2) mxslot[tid] = 0u;
-  __syncthreads();
 
   const uint4* wb = wkv + (size_t)h * nch * (8 * 64) + lane;
   float osc[4];
@@ -176,13 +173,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
       uint4 bq[8];  // this chunk's weight fragments travel while the chunk is staged
 #pragma unroll
       for (int i = 0; i < 8; ++i) bq[i] = wb[(size_t)(ch * 8 + i) * 64];
-      const float f = st.stage(tile, mxslot, ch);
-      if (f != 1.f) {
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] *= f;
-      }
+      const unsigned char* tile = st.stage(tiles_lds);
       if (ch + 1 < nch) st.issue(ch + 1);
       half8 a[4][2];
 #pragma unroll
@@ -190,13 +181,10 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
           a[mb][pl] = *reinterpret_cast<const half8*>(tile + (mb * 16 + l15) * PITCH + kg * 16 + pl * 64);
-      half8 g1s[4];
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) g1s[nb] = __builtin_bit_cast(half8, bq[nb * 2]) * (_Float16)(1.0f / 2048.0f);
 #define LA_TERM(pl, bexpr)                                                                          \
   _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) \
       acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
-      LA_TERM(1, g1s[nb])
+      LA_TERM(1, __builtin_bit_cast(half8, bq[nb * 2]))
       LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2 + 1]))
       LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2]))
 #undef LA_TERM
@@ -272,7 +260,6 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 #pragma unroll
           for (int eb = 0; eb < 2; ++eb)
             ctx[db][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[mb][db][r], acc[mb][2 + eb][r], ctx[db][eb], 0, 0, 0);
-    __syncthreads();  // the LDS tile is free for the next sub-tile
   }
 
   float* out = partial + ((size_t)(b * nsplit + sp) * 4 + h) * LA_PART;
@@ -316,25 +303,24 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
                                                             float* __restrict__ out, int n, int C, int nblk, int tiles,
                                                             float scale, FuseOut fo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tile = smem;
-  unsigned* mxslot = reinterpret_cast<unsigned*>(smem + TILE_BYTES);
-  float* yx = reinterpret_cast<float*>(smem + TILE_BYTES + 16);  // FUSE only
+  constexpr int NBUF = FUSE ? 1 : 2;
+  unsigned char* tiles_lds = smem;
+  float* yx = reinterpret_cast<float*>(smem + TILE_BYTES);  // FUSE only
 
   const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
   const int nch = C / KC;
 
-  Stager st;
+  Stager<NBUF> st;
   st.xb = x + (size_t)b * n * C;
   st.g = g;
   st.C = C;
   st.n = n;
   st.c4 = tid & 7;
   st.pix0 = tid >> 3;
+  st.init_scale();
   const float* stats_b = stats + (size_t)b * n * 2;
-  if (tid < 2) mxslot[tid] = 0u;
-  __syncthreads();
 
   const uint4* wb = wq + (size_t)h * nch * (4 * 64) + lane;
   // per-row (d = db*16 + 4*kg + r) weight unscale, and the A operand of out^T = ctx^T q^T:
@@ -352,13 +338,12 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
     }
   float* ob = out + (size_t)b * n * 128 + h * 32;
   // FUSE: to_out weight fragments of this head (A operand: rows c, K = the head's 32 channels), kept in registers
-  half8 wo1[4], wo2[4], wo1s[4];
+  half8 wo1[4], wo2[4];
   if (FUSE) {
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb) {
       wo1[cb] = __builtin_bit_cast(half8, fo.wo[((h * 4 + cb) * 2 + 0) * 64 + lane]);
       wo2[cb] = __builtin_bit_cast(half8, fo.wo[((h * 4 + cb) * 2 + 1) * 64 + lane]);
-      wo1s[cb] = wo1[cb] * (_Float16)(1.0f / 2048.0f);
     }
   }
 
@@ -379,13 +364,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       uint4 aq[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) aq[i] = wb[(size_t)(ch * 4 + i) * 64];
-      const float f = st.stage(tile, mxslot, ch);
-      if (f != 1.f) {
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-          for (int nbn = 0; nbn < 4; ++nbn) acc[db][nbn] *= f;
-      }
+      const unsigned char* tile = st.stage(tiles_lds);
       if (ch + 1 < nch) st.issue(ch + 1);
       half8 xb[4][2];
 #pragma unroll
@@ -393,13 +372,10 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
           xb[nbn][pl] = *reinterpret_cast<const half8*>(tile + (nbn * 16 + l15) * PITCH + kg * 16 + pl * 64);
-      half8 g1s[2];
-#pragma unroll
-      for (int db = 0; db < 2; ++db) g1s[db] = __builtin_bit_cast(half8, aq[db * 2]) * (_Float16)(1.0f / 2048.0f);
 #define LA_TERM(aexpr, pl)                                                                           \
   _Pragma("unroll") for (int db = 0; db < 2; ++db) _Pragma("unroll") for (int nbn = 0; nbn < 4; ++nbn) \
       acc[db][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aexpr, xb[nbn][pl], acc[db][nbn], 0, 0, 0);
-      LA_TERM(g1s[db], 1)
+      LA_TERM(__builtin_bit_cast(half8, aq[db * 2]), 1)
       LA_TERM(__builtin_bit_cast(half8, aq[db * 2 + 1]), 0)
       LA_TERM(__builtin_bit_cast(half8, aq[db * 2]), 0)
 #undef LA_TERM
@@ -480,12 +456,12 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
             const float xs = o[eb][r] * sc;
             const _Float16 a1 = (_Float16)xs;
             h1[eb * 4 + r] = a1;
-            h2[eb * 4 + r] = (_Float16)((xs - (float)a1) * 2048.f);
+            h2[eb * 4 + r] = (_Float16)(xs - (float)a1);
           }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           float4v t = float4v{0.f, 0.f, 0.f, 0.f};
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1s[cb], h2, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h2, t, 0, 0, 0);
           t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo2[cb], h1, t, 0, 0, 0);
           t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h1, t, 0, 0, 0);
           yacc[cb][nbn] = t * inv;
@@ -537,7 +513,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         }
       }
     }
-    __syncthreads();  // the LDS tile is free for the next sub-tile
+    if (FUSE) __syncthreads();  // the exchange buffer is free for the next sub-tile
   }
 }
 
@@ -649,7 +625,7 @@ extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, con
   const int tiles = fused_tiles(B, n), nsplit = cdiv(cdiv(n, TP), tiles);
   const uint4* wkv = reinterpret_cast<const uint4*>(wpack + (int64_t)C * 128);
   const float* osc_kv = wpack + (int64_t)C * 384 + 128;
-  hipLaunchKernelGGL(linattn_kv_kernel, dim3(B * nsplit), dim3(256), TILE_BYTES + 16, (hipStream_t)stream, x, stats, ln_g,
+  hipLaunchKernelGGL(linattn_kv_kernel, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
                      wkv, osc_kv, partial, n, C, nsplit, tiles);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_context");
   return DMH_OK;
@@ -664,7 +640,7 @@ extern "C" int dmh_linattn_fused_apply(const float* x, const float* stats, const
   const uint4* wq = reinterpret_cast<const uint4*>(wpack);
   const float* osc_q = wpack + (int64_t)C * 384;
   FuseOut fo = {};
-  hipLaunchKernelGGL(linattn_qo_kernel<false>, dim3(B * nblk), dim3(256), TILE_BYTES + 16, (hipStream_t)stream, x, stats,
+  hipLaunchKernelGGL(linattn_qo_kernel<false>, dim3(B * nblk), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats,
                      ln_g, wq, osc_q, ctx, out, n, C, nblk, tiles, scale, fo);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_apply");
   return DMH_OK;
@@ -737,7 +713,7 @@ extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, c
   fo.g_out = out_ln_g;
   fo.y = y;
   fo.eps = eps;
-  constexpr int LDS = TILE_BYTES + 16 + YX_BYTES;
+  constexpr int LDS = TILE_BYTES + YX_BYTES;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)linattn_qo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
