@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
                                                             float* __restrict__ out, int n, int C, int nblk, int tiles,
                                                             float scale, FuseOut fo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NBUF = FUSE ? 1 : 2;
+  constexpr int NBUF = 1;
   unsigned char* tiles_lds = smem;
   float* yx = reinterpret_cast<float*>(smem + TILE_BYTES);  // FUSE only
 
@@ -323,19 +323,45 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
   const float* stats_b = stats + (size_t)b * n * 2;
 
   const uint4* wb = wq + (size_t)h * nch * (4 * 64) + lane;
-  // per-row (d = db*16 + 4*kg + r) weight unscale, and the A operand of out^T = ctx^T q^T:
-  // A[m = e][k slot kg of step (db, r)] = ctx[d = db*16 + 4*kg + r][e = eb*16 + l15]
-  float osc[2][4], ca[2][2][4];
-  const float* cb = ctxm + (size_t)(b * 4 + h) * 1024;
+  // per-row (d = db*16 + 4*kg + r) weight unscale, and the A operand of out^T = ctx^T q'^T as block-scaled fp16 pieces
+  // (round 2; round 1 ran this product as 64 fp32 16x16x4 MFMAs per sub-tile, which execute on the vector ALUs):
+  // A[m = e][K slot 8*kg + j] = ctx[d(kg, j)][e = eb*16 + l15] with d(kg, j) = j < 4 ? 4*kg + j : 16 + 4*kg + (j - 4) — the
+  // order in which a lane of the q^T accumulators holds its 8 values of a pixel column, so q' needs no lane movement.
+  // The context of a head is fixed for the workgroup: one block maximum over its 1024 values, split once.
+  float osc[2][4];
+  half8 c1[2], c2[2];
+  float inv_c;
+  {
+    const float* cb = ctxm + (size_t)(b * 4 + h) * 1024;
+    float cv[2][8];
+    unsigned mx = 0u;
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int d = db * 16 + 4 * kg + r;
-      osc[db][r] = oscale[h * 32 + d];
+      for (int r = 0; r < 4; ++r) {
+        const int d = db * 16 + 4 * kg + r;
+        osc[db][r] = oscale[h * 32 + d];
 #pragma unroll
-      for (int eb = 0; eb < 2; ++eb) ca[eb][db][r] = cb[d * 32 + eb * 16 + l15];
-    }
+        for (int eb = 0; eb < 2; ++eb) {
+          cv[eb][db * 4 + r] = cb[d * 32 + eb * 16 + l15];
+          mx = max(mx, absbits(cv[eb][db * 4 + r]));
+        }
+      }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    const int ex = min(max((int)(mx >> 23), 32), 254);
+    const float scc = __uint_as_float((unsigned)(268 - ex) << 23);
+    inv_c = __uint_as_float((unsigned)(ex - 14 - 17) << 23);  // 1 / scc, and the 2^17 q' carries (below)
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xs = cv[eb][j] * scc;
+        const _Float16 a1 = (_Float16)xs;
+        c1[eb][j] = a1;
+        c2[eb][j] = (_Float16)(xs - (float)a1);
+      }
+  }
   float* ob = out + (size_t)b * n * 128 + h * 32;
   // FUSE: to_out weight fragments of this head (A operand: rows c, K = the head's 32 channels), kept in registers
   half8 wo1[4], wo2[4];
@@ -411,24 +437,61 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         }
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
-      const float rs = scale / s;  // one division per pixel column instead of 32 (softmax * scale, CFG:262-263)
+      // one division per pixel column instead of 32 (softmax * scale, CFG:262-263).  * 2^17 (undone in inv_c): q' <= scale
+      // < 2^-2 becomes <= 2^15, so the second fp16 piece of every q' that matters is a normal number — the matrix cores
+      // flush fp16 subnormals (measured: with q' <= 11 the residuals ~6e-5 were lost, 8e-5 relative error on some tiles)
+      const float rs = scale * 131072.f / s;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[db][nbn][r] *= rs;
+        for (int r = 0; r < 4; ++r) {
+          // The product must exist as ONE fp32 value before it is split below: hipcc otherwise forms the first piece as
+          // fp16(round32(e * rs)) for the MFMA and, through v_fma_mixlo_f16, the second one against fp16(e * rs) rounded
+          // once — the two differ by an fp16 ulp for about one value in 2^13, which showed as 3-8e-5 relative error on a
+          // few tiles (neither __fmul_rn nor `#pragma clang fp contract(off)` stops that fold; the empty asm does).
+          // Everywhere else the multiplier in front of a split is a power of two, where both forms agree.
+          float qv = acc[db][nbn][r] * rs;
+          asm volatile("" : "+v"(qv));
+          acc[db][nbn][r] = qv;
+        }
     }
     // ---- out^T[e][n] = sum_d ctx[d][e] q'[n][d]
     float4v yacc[4][4];  // FUSE: this head's part of to_out: rows c (cb, 4*kg + r), columns = pixels
+    // q' of pixel column l15 (0 <= q' * 2^17 <= 2^15) as fp16 pieces: the lane's 8 values are one K = 32 B-fragment slice
+    half8 q1[4], q2[4];
 #pragma unroll
-    for (int nbn = 0; nbn < 4; ++nbn) {
-      float4v o[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+    for (int nbn = 0; nbn < 4; ++nbn)
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+          const float qv = acc[db][nbn][r];
+          const _Float16 a1 = (_Float16)qv;
+          q1[nbn][db * 4 + r] = a1;
+          q2[nbn][db * 4 + r] = (_Float16)(qv - (float)a1);
+        }
+    // eight independent accumulation chains, term by term (a chain's MFMAs are eight instructions apart)
+    float4v ot[4][2];
 #pragma unroll
-          for (int eb = 0; eb < 2; ++eb)
-            o[eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[eb][db][r], acc[db][nbn][r], o[eb], 0, 0, 0);
+    for (int nbn = 0; nbn < 4; ++nbn)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+        ot[nbn][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1[eb], q2[nbn], float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int nbn = 0; nbn < 4; ++nbn)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+        ot[nbn][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c2[eb], q1[nbn], ot[nbn][eb], 0, 0, 0);
+#pragma unroll
+    for (int nbn = 0; nbn < 4; ++nbn)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+        ot[nbn][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1[eb], q1[nbn], ot[nbn][eb], 0, 0, 0);
+#pragma unroll
+    for (int nbn = 0; nbn < 4; ++nbn) {
+      float4v o[2];
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) o[eb] = ot[nbn][eb] * inv_c;
       if (!FUSE) {
         const int pix = p0 + nbn * 16 + l15;  // column = pixel; rows e = eb*16 + 4*kg + r: four consecutive channels
         if (pix < n) {
@@ -513,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         }
       }
     }
-    if (FUSE) __syncthreads();  // the exchange buffer is free for the next sub-tile
+    __syncthreads();  // the exchange buffer is free for the next sub-tile
   }
 }
 
