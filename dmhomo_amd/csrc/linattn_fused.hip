@@ -11,12 +11,13 @@
 // The projections are f16x3 GEMMs exactly as in conv_f16x3.hip (block-scaled fp16 pieces of the fp32 operands,
 // three v_mfma_f32_16x16x32_f16 per product block, fp32 accumulation; see that file for the error analysis); the
 // staged operand is the LayerNorm output (x - mean) * rstd * g, computed as chan_layernorm_kernel computes it from
-// the per-pixel (mean, rstd) of dmh_pixel_stats.  One wave per head; 64 pixels per sub-tile.
+// the per-pixel (mean, rstd) of dmh_pixel_stats, under a STATIC block scale (sqrt(C) * max|g| bounds it).  One wave per
+// head; 64 pixels per sub-tile.  The two attention products run on the fp16 matrix cores as well (round 2):
 //   pass 1 multiplies pixels x channels ("pixels as rows"): the accumulator layout (lane = channel, registers =
-//          pixels) is at once the A operand (exp(k - m)) and the B operand (v) of the fp32 16x16x4 MFMA that
-//          contracts over pixels — no lane movement between the two GEMMs;
-//   pass 2 multiplies channels x pixels (q^T): its accumulators (lane = pixel, registers = d) are the B operand of
-//          out^T = ctx^T q^T.
+//          pixels) is at once the A operand (exp(k - m), split into two fp16 pieces) and the B operand (v, per-column
+//          scale, two pieces) of the 16x16x32 MFMAs that contract over the pixels — no lane movement between the GEMMs;
+//   pass 2 multiplies channels x pixels (q^T): its accumulators (lane = pixel, registers = d), softmaxed and split, are
+//          the B operand of out^T = ctx^T q^T, whose A operand (the head's context) is split once per workgroup.
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -226,6 +227,12 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
       }
       m_run[db] = m_new[db];
     }
+    // ---- ctx[d][e] += sum_n p[n][d] v[n][e] on the fp16 matrix cores (round 2; round 1: 64 fp32 16x16x4 MFMAs per sub-tile,
+    // which execute on the vector ALUs).  The accumulator layout is the operand layout: lane (l15, kg) holds column l15
+    // (d for p, e for v) of the pixels mb*16 + 4*kg + r, and K slot 8*kg + j of step s is pixel (2s + (j >> 2))*16 + 4*kg
+    // + (j & 3) for A and B alike.  p = exp(k - m) lies in [0, 1]: * 2^10, split; v: per column (= per lane) power-of-two
+    // scale from the column's maximum over the sub-tile, split; the product is unscaled per lane (D columns = e = l15).
+    half8 p1[2][2], p2[2][2], v1[2][2], v2[2][2];  // [block][K step]
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       float s = 0.f;
@@ -234,32 +241,72 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float pv = __expf(acc[mb][db][r] - m_new[db]);  // exp(-inf) = 0 for pixels beyond n
-          acc[mb][db][r] = pv;
           s += pv;
+          const float ps = pv * 1024.f;
+          const _Float16 a1 = (_Float16)ps;
+          p1[db][mb >> 1][(mb & 1) * 4 + r] = a1;
+          p2[db][mb >> 1][(mb & 1) * 4 + r] = (_Float16)(ps - (float)a1);
         }
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
       s_run[db] += s;
     }
+    float inv_v[2];
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb)
+    for (int eb = 0; eb < 2; ++eb) {
+      unsigned mx = 0u;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool valid = p0 + mb * 16 + 4 * kg + r < n;
-          acc[mb][2 + eb][r] = valid ? acc[mb][2 + eb][r] * inv_s * osc[2 + eb] : 0.f;
+          const float vv = valid ? acc[mb][2 + eb][r] * inv_s * osc[2 + eb] : 0.f;
+          acc[mb][2 + eb][r] = vv;
+          mx = max(mx, absbits(vv));
         }
-    // ctx[d][e] += sum_n p[n][d] v[n][e]: K slot kg of step (mb, r) is pixel mb*16 + 4*kg + r for A and B alike
+      mx = max(mx, (unsigned)__shfl_xor((int)mx, 16));
+      mx = max(mx, (unsigned)__shfl_xor((int)mx, 32));
+      const int ex = min(max((int)(mx >> 23), 32), 254);
+      const float scv = __uint_as_float((unsigned)(268 - ex) << 23);      // column maximum * scv in [2^14, 2^15)
+      inv_v[eb] = __uint_as_float((unsigned)(ex - 14 - 10) << 23);        // 1 / scv, and the 2^10 of p
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb)
+      for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+          const float xs = acc[mb][2 + eb][r] * scv;
+          const _Float16 a1 = (_Float16)xs;
+          v1[eb][mb >> 1][(mb & 1) * 4 + r] = a1;
+          v2[eb][mb >> 1][(mb & 1) * 4 + r] = (_Float16)(xs - (float)a1);
+        }
+    }
+    float4v t[2][2];  // four independent chains, term by term
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-          for (int eb = 0; eb < 2; ++eb)
-            ctx[db][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(acc[mb][db][r], acc[mb][2 + eb][r], ctx[db][eb], 0, 0, 0);
+      for (int eb = 0; eb < 2; ++eb)
+        t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1[db][0], v2[eb][0], float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1[db][1], v2[eb][1], t[db][eb], 0, 0, 0);
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+          t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p2[db][st2], v1[eb][st2], t[db][eb], 0, 0, 0);
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int eb = 0; eb < 2; ++eb)
+          t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1[db][st2], v1[eb][st2], t[db][eb], 0, 0, 0);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) ctx[db][eb] += t[db][eb] * inv_v[eb];
   }
 
   float* out = partial + ((size_t)(b * nsplit + sp) * 4 + h) * LA_PART;
