@@ -122,6 +122,10 @@ struct Stager {
 // ------------------------------------------------------------------------------------------ pass 1
 // grid = B * nsplit workgroups; workgroup (b, sp) covers `tiles` sub-tiles of 64 pixels; wave = head.
 // wkv: [head 4][chunk][nb 4: k lo, k hi, v lo, v hi][plane 2][lane 64] x 16 B, then 256 floats 2^-k per (head, nb, col)
+// RES: number of channel chunks whose weight fragments stay in registers for the whole workgroup (2 when C == 64: the
+// 128x128 level, where a workgroup walks 4 sub-tiles and round 1 re-fetched the head's 16 KB of fragments from L2 for each
+// of them); 0: the fragments of a chunk are fetched while the chunk is staged.
+template <int RES>
 __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const uint4* __restrict__ wkv,
                                                             const float* __restrict__ oscale, float* __restrict__ partial,
@@ -161,6 +165,13 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
     st.begin_tile(stats_b, sp * tiles * TP);
     st.issue(0);
   }
+  uint4 wres[RES ? RES : 1][8];
+  if (RES) {
+#pragma unroll
+    for (int ch = 0; ch < RES; ++ch)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wres[ch][i] = wb[(size_t)(ch * 8 + i) * 64];
+  }
   for (int tI = 0; tI < tiles; ++tI) {
     const int p0 = (sp * tiles + tI) * TP;
     if (p0 >= n) break;
@@ -170,10 +181,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    for (int ch = 0; ch < nch; ++ch) {
-      uint4 bq[8];  // this chunk's weight fragments travel while the chunk is staged
-#pragma unroll
-      for (int i = 0; i < 8; ++i) bq[i] = wb[(size_t)(ch * 8 + i) * 64];
+    auto chunk = [&](int ch, const uint4 (&bq)[8]) __attribute__((always_inline)) {
       const unsigned char* tile = st.stage(tiles_lds);
       if (ch + 1 < nch) st.issue(ch + 1);
       half8 a[4][2];
@@ -189,6 +197,17 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
       LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2 + 1]))
       LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2]))
 #undef LA_TERM
+    };
+    if (RES) {
+#pragma unroll
+      for (int ch = 0; ch < RES; ++ch) chunk(ch, wres[ch]);
+    } else {
+      for (int ch = 0; ch < nch; ++ch) {
+        uint4 bq[8];  // this chunk's weight fragments travel while the chunk is staged
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bq[i] = wb[(size_t)(ch * 8 + i) * 64];
+        chunk(ch, bq);
+      }
     }
     const float inv_s = st.inv_scale();
     if (tI + 1 < tiles && p0 + TP < n) {  // the next sub-tile's first chunk travels during the softmax / context math
@@ -424,6 +443,13 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
     st.begin_tile(stats_b, blk * tiles * TP);
     st.issue(0);
   }
+  uint4 wres[2][4];
+  if (FUSE) {
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) wres[ch][i] = wb[(size_t)(ch * 4 + i) * 64];
+  }
   for (int tI = 0; tI < tiles; ++tI) {
     const int p0 = (blk * tiles + tI) * TP;
     if (p0 >= n) break;
@@ -433,10 +459,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
 #pragma unroll
       for (int nbn = 0; nbn < 4; ++nbn) acc[db][nbn] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    for (int ch = 0; ch < nch; ++ch) {
-      uint4 aq[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) aq[i] = wb[(size_t)(ch * 4 + i) * 64];
+    auto chunk = [&](int ch, const uint4 (&aq)[4]) __attribute__((always_inline)) {
       const unsigned char* tile = st.stage(tiles_lds);
       if (ch + 1 < nch) st.issue(ch + 1);
       half8 xb[4][2];
@@ -452,6 +475,17 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       LA_TERM(__builtin_bit_cast(half8, aq[db * 2 + 1]), 0)
       LA_TERM(__builtin_bit_cast(half8, aq[db * 2]), 0)
 #undef LA_TERM
+    };
+    if (FUSE) {  // C == 64: both chunks' q fragments stay in registers for the whole workgroup
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) chunk(ch, wres[ch]);
+    } else {
+      for (int ch = 0; ch < nch; ++ch) {
+        uint4 aq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aq[i] = wb[(size_t)(ch * 4 + i) * 64];
+        chunk(ch, aq);
+      }
     }
     const float inv_s = st.inv_scale();
     if (tI + 1 < tiles && p0 + TP < n) {
@@ -735,8 +769,12 @@ extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, con
   const int tiles = fused_tiles(B, n), nsplit = cdiv(cdiv(n, TP), tiles);
   const uint4* wkv = reinterpret_cast<const uint4*>(wpack + (int64_t)C * 128);
   const float* osc_kv = wpack + (int64_t)C * 384 + 128;
-  hipLaunchKernelGGL(linattn_kv_kernel, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
-                     wkv, osc_kv, partial, n, C, nsplit, tiles);
+  if (C == 2 * KC)
+    hipLaunchKernelGGL(linattn_kv_kernel<2>, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
+                       wkv, osc_kv, partial, n, C, nsplit, tiles);
+  else
+    hipLaunchKernelGGL(linattn_kv_kernel<0>, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
+                       wkv, osc_kv, partial, n, C, nsplit, tiles);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_context");
   return DMH_OK;
 }
