@@ -1,0 +1,63 @@
+"""the N > 1 data path of bench.py / scripts (dmhomo_amd/distributed.py) on the RCCL backend itself.  The pool's boxes have
+one GPU, so the process group has ONE rank — enough to run every collective the path issues (scatter + all_gather weight
+payload, broadcast of the integer buffers, all_gather of the shard sizes, gather of uint8 images and f64 homographies,
+all_reduce of gradients and of the timing) through RCCL on device tensors: dtype / op support and stream semantics, which
+the world-size-2 gloo tests on CPU cannot show.  Runs in a child process (a process group is global state)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['DMH_ROOT'])
+from dmhomo_amd import cfg, ops
+from dmhomo_amd import distributed as D
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%s' % os.environ['DMH_PORT'], rank=0, world_size=1)
+assert dist.get_backend() == 'nccl'
+D.world_size = lambda: 2                      # take the collective branch of every helper (the group itself has 1 rank)
+dev = torch.device('cuda', 0)
+torch.manual_seed(3)
+m = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1)
+d = cfg.GaussianDiffusion(m, image_size=16, timesteps=50, sampling_timesteps=4, objective='pred_x0').to(dev)
+before = {k: v.clone() for k, v in d.state_dict().items()}
+D.broadcast_module_(d, src=0)                 # scatter + all_gather + broadcast over RCCL
+for k, v in d.state_dict().items():
+    assert torch.equal(v, before[k]), k
+imgs = torch.arange(5 * 6 * 4 * 4, device=dev).reshape(5, 6, 4, 4).to(torch.uint8)
+homos = torch.randn(5, 3, 3, device=dev, dtype=torch.float64)
+gi, gh = D.gather_records(imgs, homos, dst=0)  # all_gather(int64) + gather(uint8) + gather(f64)
+assert torch.equal(gi, imgs) and torch.equal(gh, homos)
+grads = {'a': torch.randn(1000, device=dev), 'b': torch.randn(7, 3, device=dev)}
+real_ws = dist.get_world_size
+dist.get_world_size = lambda *a, **k: 2        # average_gradients' own guard
+try:
+    avg = D.average_gradients(grads, lambda flat, s: flat * s)
+finally:
+    dist.get_world_size = real_ws
+for k in grads:
+    assert torch.allclose(avg[k], grads[k] * 0.5), k   # one rank's sum, scaled by 1 / "2"
+t = torch.tensor([1.5, 2.5], device=dev, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the timing reduction of bench.py
+assert t.tolist() == [1.5, 2.5]
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print('RCCL-OK')
+'''
+
+
+def test_rccl_collectives_of_the_data_path_single_rank():
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DMH_ROOT=root, DMH_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', CHILD], capture_output=True, text=True, env=env, cwd=root, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and 'RCCL-OK' in r.stdout
