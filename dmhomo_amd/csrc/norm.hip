@@ -5,27 +5,36 @@
 // ---------------------------------------------------------------------------------------------
 // N2: reduce the per-tile (sum, sum^2) partials of dmh_conv2d for one (sample, group) in f64 and
 // emit the affine the consumer applies:  y = a*x + b  ==  ((x-mean)*rstd*gamma+beta)*(scale+1)+shift
-// One wave per (sample, group); fixed reduction order.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ stats, int tiles,
-                                                         const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ ss,
-                                                         int64_t ss_stride, float* __restrict__ coef, int C, int groups,
-                                                         int hw, float eps, float* __restrict__ mr) {
+// One workgroup of four waves per (sample, group); fixed reduction order.  (Round 1 used one wave: at 128x128 its lanes
+// walked 16 dependent rounds of partials, 6.7 us for a launch that happens 38 times per UNet pass.)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ stats, int tiles,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ ss,
+                                                          int64_t ss_stride, float* __restrict__ coef, int C, int groups,
+                                                          int hw, float eps, float* __restrict__ mr) {
+  __shared__ double red[2][4];
   const int b = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cg = C / groups;
   const int lane = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
   const int total = tiles * cg;
-  for (int i = lane; i < total; i += 64) {
+  for (int i = lane; i < total; i += 256) {
     const int tile = i / cg, cc = i % cg;
-    const float* st = stats + ((size_t)(b * tiles + tile) * C + g * cg + cc) * 2;
-    s1 += (double)st[0];
-    s2 += (double)st[1];
+    const float2 st = *reinterpret_cast<const float2*>(stats + ((size_t)(b * tiles + tile) * C + g * cg + cc) * 2);
+    s1 += (double)st.x;
+    s2 += (double)st.y;
   }
   for (int off = 32; off; off >>= 1) {
     s1 += __shfl_xor(s1, off);
     s2 += __shfl_xor(s2, off);
   }
+  if ((lane & 63) == 0) {
+    red[0][lane >> 6] = s1;
+    red[1][lane >> 6] = s2;
+  }
+  __syncthreads();
+  s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   const double n = (double)hw * (double)cg;
   const double mean = s1 / n;
   double var = s2 / n - mean * mean;
@@ -36,7 +45,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     mr[(size_t)blockIdx.x * 2 + 0] = meanf;
     mr[(size_t)blockIdx.x * 2 + 1] = rstd;
   }
-  for (int cc = lane; cc < cg; cc += 64) {
+  for (int cc = lane; cc < cg; cc += 256) {
     const int c = g * cg + cc;
     float a = rstd * gamma[c];
     float bb = beta[c] - meanf * a;
@@ -137,7 +146,7 @@ extern "C" int dmh_gn_finalize(const float* stats, int tiles, const float* gamma
                                void* stream) {
   DMH_REQUIRE(stats && gamma && beta && coef, "dmh_gn_finalize: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize: bad shape");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
                      ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr);
   DMH_CHECK_LAUNCH("dmh_gn_finalize");
   return DMH_OK;
@@ -149,7 +158,7 @@ extern "C" int dmh_gn_finalize_train(const float* stats, int tiles, const float*
                                      int groups, int hw, float eps, void* stream) {
   DMH_REQUIRE(stats && gamma && beta && coef && mr, "dmh_gn_finalize_train: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize_train: bad shape");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
                      ss, ss_stride, coef, C, groups, hw, eps, mr);
   DMH_CHECK_LAUNCH("dmh_gn_finalize_train");
   return DMH_OK;
