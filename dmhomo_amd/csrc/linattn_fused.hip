@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
                                                             float* __restrict__ out, int n, int C, int nblk, int tiles,
                                                             float scale, FuseOut fo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NBUF = 1;
+  constexpr int NBUF = FUSE ? 1 : 2;
   unsigned char* tiles_lds = smem;
   float* yx = reinterpret_cast<float*>(smem + TILE_BYTES);  // FUSE only
 
@@ -621,11 +621,19 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         for (int nbn = 0; nbn < 4; ++nbn)
           st4(yx + ((h * TP) + nbn * 16 + l15) * YP + cb * 16 + 4 * kg,
               make_float4(yacc[cb][nbn][0], yacc[cb][nbn][1], yacc[cb][nbn][2], yacc[cb][nbn][3]));
+      // the residual rows of this thread's four pixels (L2: the workgroup staged them a moment ago) are requested before the
+      // barrier, together: loaded one by one where they are added, each exposed its round trip
+      const int quad = tid & 15;
+      float4 xr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pix = min(p0 + (tid >> 4) + 16 * i, n - 1);
+        xr[i] = ld4(st.xb + (size_t)pix * 64 + quad * 4);
+      }
+      const float4 oq = ld4(fo.osc_o + quad * 4), bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
       __syncthreads();
       // 64 pixels x 16 channel quads: sum the heads, undo the weight scale, + bias, LayerNorm over the 64 channels (two
       // passes, as chan_layernorm_kernel), * g, + x
-      const int quad = tid & 15;
-      const float4 oq = ld4(fo.osc_o + quad * 4), bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int pl = (tid >> 4) + 16 * i;  // pixel of the sub-tile
@@ -647,17 +655,16 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         const float rs = 1.0f / sqrtf(qs / 64.f + fo.eps);
         const int pix = p0 + pl;
         if (pix < n) {
-          const float4 xr = ld4(st.xb + (size_t)pix * 64 + quad * 4);
           float4 r4;
-          r4.x = dx * rs * gq4.x + xr.x;
-          r4.y = dy * rs * gq4.y + xr.y;
-          r4.z = dz * rs * gq4.z + xr.z;
-          r4.w = dw * rs * gq4.w + xr.w;
+          r4.x = dx * rs * gq4.x + xr[i].x;
+          r4.y = dy * rs * gq4.y + xr[i].y;
+          r4.z = dz * rs * gq4.z + xr[i].z;
+          r4.w = dw * rs * gq4.w + xr[i].w;
           st4(fo.y + ((size_t)b * n + pix) * 64 + quad * 4, r4);
         }
       }
     }
-    __syncthreads();  // the exchange buffer is free for the next sub-tile
+    if (FUSE) __syncthreads();  // the exchange buffer is free for the next sub-tile
   }
 }
 
