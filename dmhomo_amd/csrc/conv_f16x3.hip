@@ -267,18 +267,28 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     const bool cvalid = UPS == 2 || (s1c ? ch - p.nch0 : ch) * KC + c4 * 4 < (s1c ? p.C1 : p.C0);
     const unsigned msk = cvalid ? inside_ch : 0u;
     // ---- values of this chunk (prologue applied, padding zeroed) stay in v[]; their largest magnitude -> LDS slot
+    // The prologue runs on EVERY lane (padding lanes hold real values from clamped addresses) under the one uniform
+    // condition, and the padding is cleared afterwards by a bit mask: with the lane test around it (round 1) each of the
+    // NLOAD groups was its own exec-masked region — 11 branch pairs per chunk, and four exp -> rcp chains at a time with
+    // nothing to interleave them with.
+    if (pro) {
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        v[i].x = silu_fast(fmaf(ca.x, v[i].x, cb.x));
+        v[i].y = silu_fast(fmaf(ca.y, v[i].y, cb.y));
+        v[i].z = silu_fast(fmaf(ca.z, v[i].z, cb.z));
+        v[i].w = silu_fast(fmaf(ca.w, v[i].w, cb.w));
+      }
+    }
     unsigned mx = 0u;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      float4 x = v[i];
-      if (!((msk >> i) & 1u)) {
-        x = make_float4(0.f, 0.f, 0.f, 0.f);  // padding is exactly zero: it pads the ACTIVATED tensor
-      } else if (pro) {
-        x.x = silu_fast(fmaf(ca.x, x.x, cb.x));
-        x.y = silu_fast(fmaf(ca.y, x.y, cb.y));
-        x.z = silu_fast(fmaf(ca.z, x.z, cb.z));
-        x.w = silu_fast(fmaf(ca.w, x.w, cb.w));
-      }
+      const unsigned keep = 0u - ((msk >> i) & 1u);  // padding is exactly zero: it pads the ACTIVATED tensor
+      float4 x;
+      x.x = __uint_as_float(__float_as_uint(v[i].x) & keep);
+      x.y = __uint_as_float(__float_as_uint(v[i].y) & keep);
+      x.z = __uint_as_float(__float_as_uint(v[i].z) & keep);
+      x.w = __uint_as_float(__float_as_uint(v[i].w) & keep);
       v[i] = x;
       mx = max(max(mx, absbits(x.x)), max(max(absbits(x.y), absbits(x.z)), absbits(x.w)));
     }
