@@ -145,38 +145,51 @@ struct EpilogueRows {
                                                 int mul = 1, int dy = 0, int dx = 0) {
     if (!pre) prefetch_rows<TW>(p, row_base, oy0, ox0, mul, dy, dx);
     pre = false;
+    // all 8 rows are fetched and finished on every lane; only the store and the GroupNorm partials look at the row's
+    // validity (round 1 wrapped each row in its own exec-masked region, which pinned every slab read behind the previous
+    // row's store)
+    float4 val[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) val[i] = fetch(i * 4 + rsub);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int rr = i * 4 + rsub;
-      if (okr[i]) {
-        float4 val = fetch(rr);
-        val.x = fmaf(val.x, osc.x, bias.x);  // osc == 1 unless the kernel scaled its weights: then exactly val + bias
-        val.y = fmaf(val.y, osc.y, bias.y);
-        val.z = fmaf(val.z, osc.z, bias.z);
-        val.w = fmaf(val.w, osc.w, bias.w);
-        if (p.res) {
-          if (p.res_coef) {
-            val.x += silu_fast(fmaf(ra.x, rv[i].x, rb.x));
-            val.y += silu_fast(fmaf(ra.y, rv[i].y, rb.y));
-            val.z += silu_fast(fmaf(ra.z, rv[i].z, rb.z));
-            val.w += silu_fast(fmaf(ra.w, rv[i].w, rb.w));
-          } else {
-            val.x += rv[i].x;
-            val.y += rv[i].y;
-            val.z += rv[i].z;
-            val.w += rv[i].w;
-          }
+      val[i].x = fmaf(val[i].x, osc.x, bias.x);  // osc == 1 unless the kernel scaled its weights: then exactly val + bias
+      val[i].y = fmaf(val[i].y, osc.y, bias.y);
+      val[i].z = fmaf(val[i].z, osc.z, bias.z);
+      val[i].w = fmaf(val[i].w, osc.w, bias.w);
+    }
+    if (p.res) {
+      if (p.res_coef) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          val[i].x += silu_fast(fmaf(ra.x, rv[i].x, rb.x));
+          val[i].y += silu_fast(fmaf(ra.y, rv[i].y, rb.y));
+          val[i].z += silu_fast(fmaf(ra.z, rv[i].z, rb.z));
+          val[i].w += silu_fast(fmaf(ra.w, rv[i].w, rb.w));
         }
-        st4(p.out + oo[i], val);
-        s1.x += val.x;
-        s1.y += val.y;
-        s1.z += val.z;
-        s1.w += val.w;
-        s2.x = fmaf(val.x, val.x, s2.x);
-        s2.y = fmaf(val.y, val.y, s2.y);
-        s2.z = fmaf(val.z, val.z, s2.z);
-        s2.w = fmaf(val.w, val.w, s2.w);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          val[i].x += rv[i].x;
+          val[i].y += rv[i].y;
+          val[i].z += rv[i].z;
+          val[i].w += rv[i].w;
+        }
       }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (okr[i]) st4(p.out + oo[i], val[i]);
+      const float k = okr[i] ? 1.f : 0.f;     // rows outside the image do not enter the statistics
+      const float vx = val[i].x * k, vy = val[i].y * k, vz = val[i].z * k, vw = val[i].w * k;
+      s1.x += vx;
+      s1.y += vy;
+      s1.z += vz;
+      s1.w += vw;
+      s2.x = fmaf(vx, vx, s2.x);
+      s2.y = fmaf(vy, vy, s2.y);
+      s2.z = fmaf(vz, vz, s2.z);
+      s2.w = fmaf(vw, vw, s2.w);
     }
   }
 
