@@ -38,5 +38,63 @@ __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgc
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- cross-lane reductions without the LDS crossbar.  hipcc compiles every __shfl_xor to ds_bpermute_b32 (an LDS-pipe
+// operation with its round trip, one after the other in a reduction); on gfx950 the same butterflies exist as vector-ALU
+// operations: DPP controls inside a row of 16 lanes (quad_perm = xor 1 / xor 2; row_half_mirror and row_mirror stand in for
+// xor 4 / xor 8 once the quads resp. halves are uniform), v_permlane16_swap for xor 16 and v_permlane32_swap for xor 32.
+// Every lane ends with the same bits (the butterfly is symmetric); row16_sum adds xor 1, 2, 4, 8 in that order.
+template <int CTRL>
+__device__ __forceinline__ unsigned dmh_dpp(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned dmh_xor16(unsigned v, unsigned* other) {  // (own row's value, partner row's value)
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  *other = r[1];
+  return r[0];
+}
+__device__ __forceinline__ unsigned dmh_xor32(unsigned v, unsigned* other) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  *other = r[1];
+  return r[0];
+}
+// sum / max over the 16 lanes of a row (every lane gets the result)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __uint_as_float(dmh_dpp<0xB1>(__float_as_uint(v)));   // quad_perm [1,0,3,2]
+  v += __uint_as_float(dmh_dpp<0x4E>(__float_as_uint(v)));   // quad_perm [2,3,0,1]
+  v += __uint_as_float(dmh_dpp<0x141>(__float_as_uint(v)));  // row_half_mirror
+  v += __uint_as_float(dmh_dpp<0x140>(__float_as_uint(v)));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+  v = max(v, dmh_dpp<0xB1>(v));
+  v = max(v, dmh_dpp<0x4E>(v));
+  v = max(v, dmh_dpp<0x141>(v));
+  v = max(v, dmh_dpp<0x140>(v));
+  return v;
+}
+// over the four rows of a wave: lanes l, l ^ 16, l ^ 32, l ^ 48 (every lane gets the result)
+__device__ __forceinline__ float rows_sum(float v) {
+  unsigned o;
+  unsigned a = dmh_xor16(__float_as_uint(v), &o);
+  v = __uint_as_float(a) + __uint_as_float(o);
+  a = dmh_xor32(__float_as_uint(v), &o);
+  return __uint_as_float(a) + __uint_as_float(o);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  unsigned o;
+  unsigned a = dmh_xor16(__float_as_uint(v), &o);
+  v = fmaxf(__uint_as_float(a), __uint_as_float(o));
+  a = dmh_xor32(__float_as_uint(v), &o);
+  return fmaxf(__uint_as_float(a), __uint_as_float(o));
+}
+__device__ __forceinline__ unsigned rows_max_u32(unsigned v) {
+  unsigned o;
+  unsigned a = dmh_xor16(v, &o);
+  v = max(a, o);
+  a = dmh_xor32(v, &o);
+  return max(a, o);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return rows_max_u32(row16_max_u32(v)); }
+
 // input-channel chunk width of the conv variants (must agree between pack and kernel)
 static inline int conv_kc(int KH, int stride) { return (KH == 7 || stride == 2) ? 16 : 32; }

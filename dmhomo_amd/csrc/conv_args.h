@@ -201,17 +201,14 @@ struct EpilogueRows {
     if (by < 0) by = blockIdx.y;  // (kernels that re-deal their workgroup ids pass the logical cout-tile index)
     if (!p.stats) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      s1.x += __shfl_xor(s1.x, off);
-      s1.y += __shfl_xor(s1.y, off);
-      s1.z += __shfl_xor(s1.z, off);
-      s1.w += __shfl_xor(s1.w, off);
-      s2.x += __shfl_xor(s2.x, off);
-      s2.y += __shfl_xor(s2.y, off);
-      s2.z += __shfl_xor(s2.z, off);
-      s2.w += __shfl_xor(s2.w, off);
-    }
+    s1.x = rows_sum(s1.x);
+    s1.y = rows_sum(s1.y);
+    s1.z = rows_sum(s1.z);
+    s1.w = rows_sum(s1.w);
+    s2.x = rows_sum(s2.x);
+    s2.y = rows_sum(s2.y);
+    s2.z = rows_sum(s2.z);
+    s2.w = rows_sum(s2.w);
     __syncthreads();
     float* red = lds;
     if (lane < 16) {
@@ -249,17 +246,14 @@ struct EpilogueRows {
     if (!p.stats) return;
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, tid = threadIdx.x & 255;
     lds += (threadIdx.x >> 8) * 512;
-#pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-      s1.x += __shfl_xor(s1.x, off);
-      s1.y += __shfl_xor(s1.y, off);
-      s1.z += __shfl_xor(s1.z, off);
-      s1.w += __shfl_xor(s1.w, off);
-      s2.x += __shfl_xor(s2.x, off);
-      s2.y += __shfl_xor(s2.y, off);
-      s2.z += __shfl_xor(s2.z, off);
-      s2.w += __shfl_xor(s2.w, off);
-    }
+    s1.x = rows_sum(s1.x);
+    s1.y = rows_sum(s1.y);
+    s1.z = rows_sum(s1.z);
+    s1.w = rows_sum(s1.w);
+    s2.x = rows_sum(s2.x);
+    s2.y = rows_sum(s2.y);
+    s2.z = rows_sum(s2.z);
+    s2.w = rows_sum(s2.w);
     __syncthreads();  // every wave is done with the slab: reuse LDS as the cross-wave scratch
     float* red = lds;
     if (lane < 16) {

@@ -292,8 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       v[i] = x;
       mx = max(max(mx, absbits(x.x)), max(max(absbits(x.y), absbits(x.z)), absbits(x.w)));
     }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    mx = wave_max_u32(mx);
     if (lane == 0) atomicMax(&mxslot[ch & 1], mx);
     STAMP(0)  // wait for the halo loads + prologue + block maximum
     __syncthreads();  // block maximum complete; every wave is done reading the previous chunk's tile

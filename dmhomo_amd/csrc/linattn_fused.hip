@@ -229,8 +229,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
           acc[mb][db][r] = kv;
           m = fmaxf(m, kv);
         }
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
+      m = rows_max(m);
       m_new[db] = fmaxf(m_run[db], m);
     }
     // rescale the running context rows by exp(m_run - m_new): rows live in (kg, r), the factor in lane l15 = row
@@ -266,8 +265,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
           p1[db][mb >> 1][(mb & 1) * 4 + r] = a1;
           p2[db][mb >> 1][(mb & 1) * 4 + r] = (_Float16)(ps - (float)a1);
         }
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = rows_sum(s);
       s_run[db] += s;
     }
     float inv_v[2];
@@ -283,8 +281,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
           acc[mb][2 + eb][r] = vv;
           mx = max(mx, absbits(vv));
         }
-      mx = max(mx, (unsigned)__shfl_xor((int)mx, 16));
-      mx = max(mx, (unsigned)__shfl_xor((int)mx, 32));
+      mx = rows_max_u32(mx);
       const int ex = min(max((int)(mx >> 23), 32), 254);
       const float scv = __uint_as_float((unsigned)(268 - ex) << 23);      // column maximum * scv in [2^14, 2^15)
       inv_v[eb] = __uint_as_float((unsigned)(ex - 14 - 10) << 23);        // 1 / scv, and the 2^10 of p
@@ -413,8 +410,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
           mx = max(mx, absbits(cv[eb][db * 4 + r]));
         }
       }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off));
+    mx = wave_max_u32(mx);
     const int ex = min(max((int)(mx >> 23), 32), 254);
     const float scc = __uint_as_float((unsigned)(268 - ex) << 23);
     inv_c = __uint_as_float((unsigned)(ex - 14 - 17) << 23);  // 1 / scc, and the 2^17 q' carries (below)
@@ -505,8 +501,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
           acc[db][nbn][r] = qv;
           m = fmaxf(m, qv);
         }
-      m = fmaxf(m, __shfl_xor(m, 16));
-      m = fmaxf(m, __shfl_xor(m, 32));
+      m = rows_max(m);
       float s = 0.f;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
@@ -516,8 +511,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
           acc[db][nbn][r] = e;
           s += e;
         }
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
+      s = rows_sum(s);
       // one division per pixel column instead of 32 (softmax * scale, CFG:262-263).  * 2^17 (undone in inv_c): q' <= scale
       // < 2^-2 becomes <= 2^15, so the second fp16 piece of every q' that matters is a normal number — the matrix cores
       // flush fp16 subnormals (measured: with q' <= 11 the residuals ~6e-5 were lost, 8e-5 relative error on some tiles)
@@ -588,8 +582,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) mx = max(mx, absbits(o[eb][r]));
-        mx = max(mx, (unsigned)__shfl_xor((int)mx, 16));
-        mx = max(mx, (unsigned)__shfl_xor((int)mx, 32));
+        mx = rows_max_u32(mx);
         const int ex = min(max((int)(mx >> 23), 16), 254);
         const float sc = __uint_as_float((unsigned)(268 - ex) << 23), inv = __uint_as_float((unsigned)(ex - 14) << 23);
         half8 h1, h2;
@@ -645,13 +638,11 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         v.z = fmaf((y0.z + y1.z) + (y2.z + y3.z), oq.z, bq4.z);
         v.w = fmaf((y0.w + y1.w) + (y2.w + y3.w), oq.w, bq4.w);
         float sm = (v.x + v.y) + (v.z + v.w);
-#pragma unroll
-        for (int off = 8; off; off >>= 1) sm += __shfl_xor(sm, off);
+        sm = row16_sum(sm);
         const float mean = sm / 64.f;
         const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
         float qs = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-#pragma unroll
-        for (int off = 8; off; off >>= 1) qs += __shfl_xor(qs, off);
+        qs = row16_sum(qs);
         const float rs = 1.0f / sqrtf(qs / 64.f + fo.eps);
         const int pix = p0 + pl;
         if (pix < n) {
