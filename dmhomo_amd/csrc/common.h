@@ -95,6 +95,25 @@ __device__ __forceinline__ unsigned rows_max_u32(unsigned v) {
   return max(a, o);
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return rows_max_u32(row16_max_u32(v)); }
+// sum over aligned groups of LPP = 2 .. 64 lanes (a power of two)
+template <int LPP>
+__device__ __forceinline__ float lanes_sum(float v) {
+  static_assert(LPP >= 1 && LPP <= 64 && (LPP & (LPP - 1)) == 0, "a power of two up to 64 lanes");
+  if (LPP >= 2) v += __uint_as_float(dmh_dpp<0xB1>(__float_as_uint(v)));
+  if (LPP >= 4) v += __uint_as_float(dmh_dpp<0x4E>(__float_as_uint(v)));
+  if (LPP >= 8) v += __uint_as_float(dmh_dpp<0x141>(__float_as_uint(v)));
+  if (LPP >= 16) v += __uint_as_float(dmh_dpp<0x140>(__float_as_uint(v)));
+  unsigned o;
+  if (LPP >= 32) {
+    const unsigned a = dmh_xor16(__float_as_uint(v), &o);
+    v = __uint_as_float(a) + __uint_as_float(o);
+  }
+  if (LPP >= 64) {
+    const unsigned a = dmh_xor32(__float_as_uint(v), &o);
+    v = __uint_as_float(a) + __uint_as_float(o);
+  }
+  return v;
+}
 
 // input-channel chunk width of the conv variants (must agree between pack and kernel)
 static inline int conv_kc(int KH, int stride) { return (KH == 7 || stride == 2) ? 16 : 32; }

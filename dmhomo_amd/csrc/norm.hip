@@ -103,8 +103,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __rest
       if (q < C4) v[j] = ld4(x + pix * C + q * 4);
       s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
-#pragma unroll
-    for (int off = LPP >> 1; off; off >>= 1) s += __shfl_xor(s, off);
+    s = lanes_sum<LPP>(s);
     const float mean = s / (float)C;
     float qsum = 0.f;
 #pragma unroll
@@ -115,8 +114,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __rest
         qsum += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
     }
-#pragma unroll
-    for (int off = LPP >> 1; off; off >>= 1) qsum += __shfl_xor(qsum, off);
+    qsum = lanes_sum<LPP>(qsum);
     const float rstd = 1.0f / sqrtf(qsum / (float)C + eps);
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -207,8 +205,7 @@ __global__ __launch_bounds__(256) void pixel_stats_kernel(const float* __restric
       if (q < C4) v[j] = ld4(x + pix * C + q * 4);
       s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
-#pragma unroll
-    for (int off = LPP >> 1; off; off >>= 1) s += __shfl_xor(s, off);
+    s = lanes_sum<LPP>(s);
     const float mean = s / (float)C;
     float qsum = 0.f;
 #pragma unroll
@@ -219,8 +216,7 @@ __global__ __launch_bounds__(256) void pixel_stats_kernel(const float* __restric
         qsum += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
     }
-#pragma unroll
-    for (int off = LPP >> 1; off; off >>= 1) qsum += __shfl_xor(qsum, off);
+    qsum = lanes_sum<LPP>(qsum);
     if (sub == 0) {
       stats[pix * 2 + 0] = mean;
       stats[pix * 2 + 1] = 1.0f / sqrtf(qsum / (float)C + eps);
