@@ -35,31 +35,50 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
                                                          int64_t npix, int HW, int C) {
   const int sub = threadIdx.x & 15;
   const int C4 = C >> 2;
+  // C <= 64 (the DGM UNet): a lane owns ONE channel quad, so its COUT weight quads are loaded once, not once per pixel
+  const bool one = C4 <= 16;
+  float4 wq[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) wq[o] = (one && sub < C4) ? ld4(w + (size_t)o * C + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float bo = 0.f;   // lane o of a pixel's 16 writes output channel o
+#pragma unroll
+  for (int o = 0; o < COUT; ++o)
+    if (sub == o && bias) bo = bias[o];
   for (int64_t pix = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (int64_t)gridDim.x * 16) {
     float acc[COUT];
 #pragma unroll
     for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
-    for (int q = sub; q < C4; q += 16) {
-      const float4 v = ld4(x + pix * C + q * 4);
+    if (one) {
+      const float4 v = sub < C4 ? ld4(x + pix * C + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int o = 0; o < COUT; ++o) {
-        const float4 ww = ld4(w + (size_t)o * C + q * 4);
-        acc[o] = fmaf(v.x, ww.x, acc[o]);
-        acc[o] = fmaf(v.y, ww.y, acc[o]);
-        acc[o] = fmaf(v.z, ww.z, acc[o]);
-        acc[o] = fmaf(v.w, ww.w, acc[o]);
+        acc[o] = fmaf(v.x, wq[o].x, acc[o]);
+        acc[o] = fmaf(v.y, wq[o].y, acc[o]);
+        acc[o] = fmaf(v.z, wq[o].z, acc[o]);
+        acc[o] = fmaf(v.w, wq[o].w, acc[o]);
+      }
+    } else {
+      for (int q = sub; q < C4; q += 16) {
+        const float4 v = ld4(x + pix * C + q * 4);
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+          const float4 ww = ld4(w + (size_t)o * C + q * 4);
+          acc[o] = fmaf(v.x, ww.x, acc[o]);
+          acc[o] = fmaf(v.y, ww.y, acc[o]);
+          acc[o] = fmaf(v.z, ww.z, acc[o]);
+          acc[o] = fmaf(v.w, ww.w, acc[o]);
+        }
       }
     }
+    float mine = 0.f;
 #pragma unroll
     for (int o = 0; o < COUT; ++o) {
-#pragma unroll
-      for (int off = 8; off; off >>= 1) acc[o] += __shfl_xor(acc[o], off);
+      const float t = row16_sum(acc[o]);   // (every lane of the pixel gets the sum)
+      mine = sub == o ? t : mine;
     }
-    if (sub == 0) {
-      const int64_t r = pix / HW;
-      const int p = (int)(pix % HW);
-#pragma unroll
-      for (int o = 0; o < COUT; ++o) out[((size_t)r * COUT + o) * HW + p] = acc[o] + (bias ? bias[o] : 0.f);
+    if (sub < COUT) {
+      const unsigned r = (unsigned)pix / (unsigned)HW, p = (unsigned)pix - r * (unsigned)HW;   // (npix < 2^31: checked at launch)
+      out[((size_t)r * COUT + sub) * HW + p] = mine + bo;
     }
   }
 }
@@ -199,6 +218,7 @@ extern "C" int dmh_final_conv_nchw(const float* x, const float* w, const float* 
                                    int Cout, void* stream) {
   DMH_REQUIRE(x && w && out && R > 0 && HW > 0 && C > 0 && C % 4 == 0, "dmh_final_conv_nchw: bad arguments");
   const int64_t npix = (int64_t)R * HW;
+  DMH_REQUIRE(npix < ((int64_t)1 << 31), "dmh_final_conv_nchw: %lld pixels (limit 2^31)", (long long)npix);
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(grid_for(npix, 16));
 #define DMH_FC(N)                                                                                             \
