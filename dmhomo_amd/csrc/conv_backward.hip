@@ -149,8 +149,7 @@ __global__ __launch_bounds__(256, NCB == 4 ? 2 : 1) void conv_wgrad_kernel(WgArg
       for (int r = 0; r < 4; ++r)
         pw[((size_t)(wave * 16 + 4 * kg + r) * 64 + cb * 16 + l15) * NT + t] = acc[t][cb][r];
   if (ct == 0) {
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
+    bsum = rows_sum(bsum);
     if (kg == 0) p.part_b[((size_t)split * (gridDim.y / p.ctiles) + ot) * 64 + wave * 16 + l15] = bsum;
   }
 }
@@ -311,11 +310,8 @@ __global__ __launch_bounds__(256, NCBW == 1 ? 3 : 2) void conv_wgrad_f16x3_kerne
       bsum.z += dv[j].z;
       bsum.w += dv[j].w;
     }
-#pragma unroll
-    for (int off = 32; off; off >>= 1) {
-      md = fmaxf(md, __shfl_xor(md, off));
-      mxx = fmaxf(mxx, __shfl_xor(mxx, off));
-    }
+    md = __uint_as_float(wave_max_u32(__float_as_uint(md)));     // (magnitudes: their bit patterns order like the values)
+    mxx = __uint_as_float(wave_max_u32(__float_as_uint(mxx)));
     if (lane == 0) {
       atomicMax(&mx[par * 2 + 0], __float_as_uint(md));
       atomicMax(&mx[par * 2 + 1], __float_as_uint(mxx));

@@ -282,8 +282,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __
       }
       s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
-#pragma unroll
-    for (int off = LPP >> 1; off; off >>= 1) s += __shfl_xor(s, off);
+    s = lanes_sum<LPP>(s);
     const float mean = s / (float)C;
     float qsum = 0.f;
 #pragma unroll
@@ -294,8 +293,7 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __
         qsum += (ex * ex + ey * ey) + (ez * ez + ew * ew);
       }
     }
-#pragma unroll
-    for (int off = LPP >> 1; off; off >>= 1) qsum += __shfl_xor(qsum, off);
+    qsum = lanes_sum<LPP>(qsum);
     const float rstd = 1.0f / sqrtf(qsum / (float)C + eps);
     float m1 = 0.f, m2 = 0.f;
     float4 xh[NV], dxh[NV];
@@ -316,11 +314,8 @@ __global__ __launch_bounds__(256) void chan_layernorm_bwd_kernel(const float* __
         dgacc[j].w = fmaf(d[j].w, xh[j].w, dgacc[j].w);
       }
     }
-#pragma unroll
-    for (int off = LPP >> 1; off; off >>= 1) {
-      m1 += __shfl_xor(m1, off);
-      m2 += __shfl_xor(m2, off);
-    }
+    m1 = lanes_sum<LPP>(m1);
+    m2 = lanes_sum<LPP>(m2);
     m1 /= (float)C;
     m2 /= (float)C;
 #pragma unroll
