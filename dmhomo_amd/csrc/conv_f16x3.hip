@@ -166,7 +166,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 
   const int nchunks = p.nch0 + p.nch1;
   const int nsteps = nchunks * NTAPS * 2;
-  const uint4* wbase = reinterpret_cast<const uint4*>(p.wpack) + (size_t)nt * nsteps * STEP_U4 + lane;
+  // (the wave's weight stream starts at a wave-uniform address: kept in scalar registers, so a step's fragment loads are
+  //  scalar base + lane offset and the walk through the steps costs no vector instructions)
+  const uint4* wbase = reinterpret_cast<const uint4*>(p.wpack) + (size_t)__builtin_amdgcn_readfirstlane(nt) * nsteps * STEP_U4;
 
   // B fragments of one step = (tap, half of the 64 output channels): [column block][plane g1, g2]; NB buffers rotate
   // over the steps, so the loads run NB - 1 steps (two for 3x3) ahead of their use.
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     if (ch_ >= nchunks) ch_ = nchunks - 1;          // (past the end: a harmless re-load)
     const uint4* src = wbase + ((size_t)(ch_ * NTAPS + tap_of(st_ >> 1)) * 2 + (st_ & 1)) * STEP_U4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bq[buf][i] = src[i * 64];
+    for (int i = 0; i < 4; ++i) bq[buf][i] = src[i * 64 + lane];
   };
 #pragma unroll
   for (int i = 0; i < NB - 1; ++i) load_b(i, 0, i);
