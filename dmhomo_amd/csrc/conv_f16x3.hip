@@ -330,13 +330,21 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       if ((i + 1) * 256 <= IN_PIX * 8 || ((tid + i * 256) >> 3) < IN_PIX) {
-        const float4v xs = float4v{v[i].x, v[i].y, v[i].z, v[i].w} * sc;
-        const half4 h1 = __builtin_convertvector(xs, half4);
-        const float4v rs = xs - __builtin_convertvector(h1, float4v);   // (exact; see the header: stored unscaled)
-        const half4 h2 = __builtin_convertvector(rs, half4);
+        // h1 = fp16(x * sc), h2 = fp16(x * sc - h1) (exact; see the header: stored unscaled) as eight v_fma_mix — each
+        // multiplies, subtracts the fp16 piece and converts in one instruction; hipcc's own sequence for the same values
+        // (packed multiply, convert, convert back, packed fma, convert) is twelve
+        uint2 h1, h2;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1.x) : "v"(v[i].x), "v"(sc));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1.x) : "v"(v[i].y), "v"(sc));
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1.y) : "v"(v[i].z), "v"(sc));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1.y) : "v"(v[i].w), "v"(sc));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h2.x) : "v"(v[i].x), "v"(sc), "v"(h1.x));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h2.x) : "v"(v[i].y), "v"(sc), "v"(h1.x));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h2.y) : "v"(v[i].z), "v"(sc), "v"(h1.y));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h2.y) : "v"(v[i].w), "v"(sc), "v"(h1.y));
         unsigned char* dst = in_tile + wroff[i];
-        *reinterpret_cast<half4*>(dst) = h1;
-        *reinterpret_cast<half4*>(dst + 64) = h2;
+        *reinterpret_cast<uint2*>(dst) = h1;
+        *reinterpret_cast<uint2*>(dst + 64) = h2;
       }
       if (more) issue_one(i);
     }
