@@ -115,5 +115,27 @@ __device__ __forceinline__ float lanes_sum(float v) {
   return v;
 }
 
+// ---- the two fp16 pieces of x * s:  h = fp16(x * s),  r = fp16(x * s - h)  (pairs packed into dwords, low half first).
+// Four v_fma_mix per pair: each multiplies, subtracts the fp16 piece and converts in ONE instruction and from the UNROUNDED
+// product, so h + r carries 22 bits of x * s whatever s is (hipcc's own sequence for the C expression — packed multiply,
+// convert, convert back, packed fma, convert — is six per pair, and for a multiplier that is not a power of two it has been
+// seen to form the two pieces from differently rounded products: linattn_fused.hip).
+__device__ __forceinline__ void dmh_split2(float x0, float x1, float s, unsigned& h, unsigned& r) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(s), "v"(h));
+}
+typedef _Float16 dmh_half8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void dmh_split8(const float (&x)[8], float s, dmh_half8& h, dmh_half8& r) {
+  uint4 hh, rr;
+  dmh_split2(x[0], x[1], s, hh.x, rr.x);
+  dmh_split2(x[2], x[3], s, hh.y, rr.y);
+  dmh_split2(x[4], x[5], s, hh.z, rr.z);
+  dmh_split2(x[6], x[7], s, hh.w, rr.w);
+  h = __builtin_bit_cast(dmh_half8, hh);
+  r = __builtin_bit_cast(dmh_half8, rr);
+}
+
 // input-channel chunk width of the conv variants (must agree between pack and kernel)
 static inline int conv_kc(int KH, int stride) { return (KH == 7 || stride == 2) ? 16 : 32; }

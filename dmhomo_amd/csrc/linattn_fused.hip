@@ -103,13 +103,12 @@ struct Stager {
       } else {
         x = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      const float4v xs = float4v{x.x, x.y, x.z, x.w} * sc;
-      const half4 h1 = __builtin_convertvector(xs, half4);
-      const float4v rs = xs - __builtin_convertvector(h1, float4v);   // exact; stored unscaled (conv_f16x3.hip)
-      const half4 h2 = __builtin_convertvector(rs, half4);
+      uint2 h1, h2;                                        // second piece stored unscaled (conv_f16x3.hip)
+      dmh_split2(x.x, x.y, sc, h1.x, h2.x);
+      dmh_split2(x.z, x.w, sc, h1.y, h2.y);
       unsigned char* dst = tile + (pix0 + 32 * i) * PITCH + c4 * 8;
-      *reinterpret_cast<half4*>(dst) = h1;
-      *reinterpret_cast<half4*>(dst + 64) = h2;
+      *reinterpret_cast<uint2*>(dst) = h1;
+      *reinterpret_cast<uint2*>(dst + 64) = h2;
     }
     __syncthreads();
     return tile;
@@ -255,16 +254,15 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
     for (int db = 0; db < 2; ++db) {
       float s = 0.f;
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int ks = 0; ks < 2; ++ks) {
+        float pv[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __expf(acc[mb][db][r] - m_new[db]);  // exp(-inf) = 0 for pixels beyond n
-          s += pv;
-          const float ps = pv * 1024.f;
-          const _Float16 a1 = (_Float16)ps;
-          p1[db][mb >> 1][(mb & 1) * 4 + r] = a1;
-          p2[db][mb >> 1][(mb & 1) * 4 + r] = (_Float16)(ps - (float)a1);
+        for (int j = 0; j < 8; ++j) {
+          pv[j] = __expf(acc[2 * ks + (j >> 2)][db][j & 3] - m_new[db]);  // exp(-inf) = 0 for pixels beyond n
+          s += pv[j];
         }
+        dmh_split8(pv, 1024.f, p1[db][ks], p2[db][ks]);
+      }
       s = rows_sum(s);
       s_run[db] += s;
     }
@@ -286,14 +284,12 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
       const float scv = __uint_as_float((unsigned)(268 - ex) << 23);      // column maximum * scv in [2^14, 2^15)
       inv_v[eb] = __uint_as_float((unsigned)(ex - 14 - 10) << 23);        // 1 / scv, and the 2^10 of p
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+      for (int ks = 0; ks < 2; ++ks) {
+        float vv[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float xs = acc[mb][2 + eb][r] * scv;
-          const _Float16 a1 = (_Float16)xs;
-          v1[eb][mb >> 1][(mb & 1) * 4 + r] = a1;
-          v2[eb][mb >> 1][(mb & 1) * 4 + r] = (_Float16)(xs - (float)a1);
-        }
+        for (int j = 0; j < 8; ++j) vv[j] = acc[2 * ks + (j >> 2)][2 + eb][j & 3];
+        dmh_split8(vv, scv, v1[eb][ks], v2[eb][ks]);
+      }
     }
     float4v t[2][2];  // four independent chains, term by term
 #pragma unroll
@@ -415,14 +411,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
     const float scc = __uint_as_float((unsigned)(268 - ex) << 23);
     inv_c = __uint_as_float((unsigned)(ex - 14 - 17) << 23);  // 1 / scc, and the 2^17 q' carries (below)
 #pragma unroll
-    for (int eb = 0; eb < 2; ++eb)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float xs = cv[eb][j] * scc;
-        const _Float16 a1 = (_Float16)xs;
-        c1[eb][j] = a1;
-        c2[eb][j] = (_Float16)(xs - (float)a1);
-      }
+    for (int eb = 0; eb < 2; ++eb) dmh_split8(cv[eb], scc, c1[eb], c2[eb]);
   }
   float* ob = out + (size_t)b * n * 128 + h * 32;
   // FUSE: to_out weight fragments of this head (A operand: rows c, K = the head's 32 channels), kept in registers
@@ -490,6 +479,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
     }
 
     // ---- q' = softmax over the 32 d of each pixel column, * scale
+    float rsv[4];
 #pragma unroll
     for (int nbn = 0; nbn < 4; ++nbn) {
       float m = -INFINITY;
@@ -513,38 +503,20 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         }
       s = rows_sum(s);
       // one division per pixel column instead of 32 (softmax * scale, CFG:262-263).  * 2^17 (undone in inv_c): q' <= scale
-      // < 2^-2 becomes <= 2^15, so the second fp16 piece of every q' that matters is a normal number — the matrix cores
-      // flush fp16 subnormals (measured: with q' <= 11 the residuals ~6e-5 were lost, 8e-5 relative error on some tiles)
-      const float rs = scale * 131072.f / s;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // The product must exist as ONE fp32 value before it is split below: hipcc otherwise forms the first piece as
-          // fp16(round32(e * rs)) for the MFMA and, through v_fma_mixlo_f16, the second one against fp16(e * rs) rounded
-          // once — the two differ by an fp16 ulp for about one value in 2^13, which showed as 3-8e-5 relative error on a
-          // few tiles (neither __fmul_rn nor `#pragma clang fp contract(off)` stops that fold; the empty asm does).
-          // Everywhere else the multiplier in front of a split is a power of two, where both forms agree.
-          float qv = acc[db][nbn][r] * rs;
-          asm volatile("" : "+v"(qv));
-          acc[db][nbn][r] = qv;
-        }
+      // < 2^-2 becomes <= 2^15, so the second fp16 piece of every q' that matters is a normal fp16 number
+      rsv[nbn] = scale * 131072.f / s;   // (the split below multiplies: q' = e * rs as two fp16 pieces of the exact product)
     }
     // ---- out^T[e][n] = sum_d ctx[d][e] q'[n][d]
     float4v yacc[4][4];  // FUSE: this head's part of to_out: rows c (cb, 4*kg + r), columns = pixels
     // q' of pixel column l15 (0 <= q' * 2^17 <= 2^15) as fp16 pieces: the lane's 8 values are one K = 32 B-fragment slice
     half8 q1[4], q2[4];
 #pragma unroll
-    for (int nbn = 0; nbn < 4; ++nbn)
+    for (int nbn = 0; nbn < 4; ++nbn) {
+      float e8[8];
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float qv = acc[db][nbn][r];
-          const _Float16 a1 = (_Float16)qv;
-          q1[nbn][db * 4 + r] = a1;
-          q2[nbn][db * 4 + r] = (_Float16)(qv - (float)a1);
-        }
+      for (int j = 0; j < 8; ++j) e8[j] = acc[j >> 2][nbn][j & 3];
+      dmh_split8(e8, rsv[nbn], q1[nbn], q2[nbn]);
+    }
     // eight independent accumulation chains, term by term (a chain's MFMAs are eight instructions apart)
     float4v ot[4][2];
 #pragma unroll
@@ -586,15 +558,12 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         const int ex = min(max((int)(mx >> 23), 16), 254);
         const float sc = __uint_as_float((unsigned)(268 - ex) << 23), inv = __uint_as_float((unsigned)(ex - 14) << 23);
         half8 h1, h2;
+        {
+          float o8[8];
 #pragma unroll
-        for (int eb = 0; eb < 2; ++eb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float xs = o[eb][r] * sc;
-            const _Float16 a1 = (_Float16)xs;
-            h1[eb * 4 + r] = a1;
-            h2[eb * 4 + r] = (_Float16)(xs - (float)a1);
-          }
+          for (int j = 0; j < 8; ++j) o8[j] = o[j >> 2][j & 3];
+          dmh_split8(o8, sc, h1, h2);
+        }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           float4v t = float4v{0.f, 0.f, 0.f, 0.f};
