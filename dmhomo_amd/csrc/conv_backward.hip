@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, NCB == 4 ? 2 : 1) void conv_wgrad_kernel(WgArg
 // forms the three kx operands in registers (v_alignbit for the odd shift, plain re-indexing for the even one).
 // Scales: per workgroup, running maxima of |dY| and |X| over its items (as in conv_f16x3.hip): when a later item raises a
 // maximum the accumulators are multiplied by the (power-of-two) ratio, so the scale only shrinks and nothing overflows.
-//     d1 = fp16(d*sd)  d2 = fp16(d*sd - d1)  d1s = d1 * 2^-11 (registers)      x1 = fp16(x*sx)  x2 = fp16((x*sx - x1) * 2^11)
-//     d*x*sd*sx = d1*x1 + d2*x1 + d1s*x2 + O(2^-22)
+//     d1 = fp16(d*sd)  d2 = fp16(d*sd - d1)      x1 = fp16(x*sx)  x2 = fp16(x*sx - x1)      (dmh_split2: four v_fma_mix per pair)
+//     d*x*sd*sx = d1*x1 + d2*x1 + d1*x2 + O(2^-22)
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
@@ -334,30 +334,26 @@ __global__ __launch_bounds__(256, NCBW == 1 ? 3 : 2) void conv_wgrad_f16x3_kerne
       const int pixb = ((pg >> 2) * TW + (pg & 3) * 4) * 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        half4 h1, h2;
+        float e[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = (i == 0 ? dv[j].x : i == 1 ? dv[j].y : i == 2 ? dv[j].z : dv[j].w) * sd;
-          const _Float16 t1 = (_Float16)v;
-          h1[j] = t1;
-          h2[j] = (_Float16)(v - (float)t1);
-        }
-        *reinterpret_cast<half4*>(a1 + (q4 * 4 + i) * APITCH + pixb) = h1;
-        *reinterpret_cast<half4*>(a2 + (q4 * 4 + i) * APITCH + pixb) = h2;
+        for (int j = 0; j < 4; ++j) e[j] = i == 0 ? dv[j].x : i == 1 ? dv[j].y : i == 2 ? dv[j].z : dv[j].w;
+        uint2 h1, h2;
+        dmh_split2(e[0], e[1], sd, h1.x, h2.x);
+        dmh_split2(e[2], e[3], sd, h1.y, h2.y);
+        *reinterpret_cast<uint2*>(a1 + (q4 * 4 + i) * APITCH + pixb) = h1;
+        *reinterpret_cast<uint2*>(a2 + (q4 * 4 + i) * APITCH + pixb) = h2;
       }
       if (xslot) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          half4 h1, h2;
+          float e[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float v = (i == 0 ? xv[j].x : i == 1 ? xv[j].y : i == 2 ? xv[j].z : xv[j].w) * sx_;
-            const _Float16 t1 = (_Float16)v;
-            h1[j] = t1;
-            h2[j] = (_Float16)((v - (float)t1) * 2048.f);
-          }
-          *reinterpret_cast<half4*>(x1 + (xq * 4 + i) * XPITCH + xrow * XROWB + xg * 8) = h1;
-          *reinterpret_cast<half4*>(x2 + (xq * 4 + i) * XPITCH + xrow * XROWB + xg * 8) = h2;
+          for (int j = 0; j < 4; ++j) e[j] = i == 0 ? xv[j].x : i == 1 ? xv[j].y : i == 2 ? xv[j].z : xv[j].w;
+          uint2 h1, h2;   // (second piece unscaled, as everywhere since round 2: conv_f16x3.hip)
+          dmh_split2(e[0], e[1], sx_, h1.x, h2.x);
+          dmh_split2(e[2], e[3], sx_, h1.y, h2.y);
+          *reinterpret_cast<uint2*>(x1 + (xq * 4 + i) * XPITCH + xrow * XROWB + xg * 8) = h1;
+          *reinterpret_cast<uint2*>(x2 + (xq * 4 + i) * XPITCH + xrow * XROWB + xg * 8) = h2;
         }
       }
     }
@@ -368,13 +364,12 @@ __global__ __launch_bounds__(256, NCBW == 1 ? 3 : 2) void conv_wgrad_f16x3_kerne
     if (!(p.ablate & 1))
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        half8 d1[OBW], d2[OBW], d1s[OBW];
+        half8 d1[OBW], d2[OBW];
 #pragma unroll
         for (int i = 0; i < OBW; ++i) {
           const char* ap = a1 + ((obg * OBW + i) * 16 + l15) * APITCH + (kg * TW + half * 8) * 2;
           d1[i] = *reinterpret_cast<const half8*>(ap);
           d2[i] = *reinterpret_cast<const half8*>(ap + Cfg::A_BYTES);
-          d1s[i] = d1[i] * (_Float16)(1.0f / 2048.0f);
         }
 #pragma unroll
         for (int ky = 0; ky < KH; ++ky) {
@@ -407,7 +402,7 @@ __global__ __launch_bounds__(256, NCBW == 1 ? 3 : 2) void conv_wgrad_f16x3_kerne
           for (int i = 0; i < OBW; ++i)
 #pragma unroll
             for (int kx = 0; kx < KH; ++kx)
-              acc[i][ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1s[i], b2[kx], acc[i][ky * KH + kx], 0, 0, 0);
+              acc[i][ky * KH + kx] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1[i], b2[kx], acc[i][ky * KH + kx], 0, 0, 0);
 #pragma unroll
           for (int i = 0; i < OBW; ++i)
 #pragma unroll
