@@ -282,18 +282,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
         v[i].w = silu_fast(fmaf(ca.w, v[i].w, cb.w));
       }
     }
-    unsigned mx = 0u;
+    // block maximum over everything the lanes hold, padding lanes included (their values are real ones from clamped
+    // addresses: the scale only has to bound the tile, and an over-estimate costs nothing — see the header); the padding
+    // itself becomes zero in the split below, which multiplies it by 0 instead of the block scale
+    float mxf = 0.f;
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      const unsigned keep = 0u - ((msk >> i) & 1u);  // padding is exactly zero: it pads the ACTIVATED tensor
-      float4 x;
-      x.x = __uint_as_float(__float_as_uint(v[i].x) & keep);
-      x.y = __uint_as_float(__float_as_uint(v[i].y) & keep);
-      x.z = __uint_as_float(__float_as_uint(v[i].z) & keep);
-      x.w = __uint_as_float(__float_as_uint(v[i].w) & keep);
-      v[i] = x;
-      mx = max(max(mx, absbits(x.x)), max(max(absbits(x.y), absbits(x.z)), absbits(x.w)));
-    }
+    for (int i = 0; i < NLOAD; ++i)
+      mxf = fmaxf(fmaxf(mxf, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+    unsigned mx = __float_as_uint(mxf);
     mx = wave_max_u32(mx);
     if (lane == 0) atomicMax(&mxslot[ch & 1], mx);
     STAMP(0)  // wait for the halo loads + prologue + block maximum
@@ -333,15 +329,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
         // h1 = fp16(x * sc), h2 = fp16(x * sc - h1) (exact; see the header: stored unscaled) as eight v_fma_mix — each
         // multiplies, subtracts the fp16 piece and converts in one instruction; hipcc's own sequence for the same values
         // (packed multiply, convert, convert back, packed fma, convert) is twelve
+        const float si = ((msk >> i) & 1u) ? sc : 0.f;   // padding is exactly zero: it pads the ACTIVATED tensor
         uint2 h1, h2;
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1.x) : "v"(v[i].x), "v"(sc));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1.x) : "v"(v[i].y), "v"(sc));
-        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1.y) : "v"(v[i].z), "v"(sc));
-        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1.y) : "v"(v[i].w), "v"(sc));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h2.x) : "v"(v[i].x), "v"(sc), "v"(h1.x));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h2.x) : "v"(v[i].y), "v"(sc), "v"(h1.x));
-        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(h2.y) : "v"(v[i].z), "v"(sc), "v"(h1.y));
-        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(h2.y) : "v"(v[i].w), "v"(sc), "v"(h1.y));
+        dmh_split2(v[i].x, v[i].y, si, h1.x, h2.x);
+        dmh_split2(v[i].z, v[i].w, si, h1.y, h2.y);
         unsigned char* dst = in_tile + wroff[i];
         *reinterpret_cast<uint2*>(dst) = h1;
         *reinterpret_cast<uint2*>(dst + 64) = h2;
