@@ -435,6 +435,18 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
 #pragma unroll
       for (int i = 0; i < 4; ++i) wres[ch][i] = wb[(size_t)(ch * 4 + i) * 64];
   }
+#ifdef DMH_STAMPS
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev, t_now;
+#define LSTAMP(i)                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  tk[i] += t_now - t_prev;                                                       \
+  t_prev = t_now;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#else
+#define LSTAMP(i)
+#endif
   for (int tI = 0; tI < tiles; ++tI) {
     const int p0 = (blk * tiles + tI) * TP;
     if (p0 >= n) break;
@@ -473,11 +485,17 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       }
     }
     const float inv_s = st.inv_scale();
+    float qsc[2][4];   // 1 / block scale, the weight row's 2^-k and log2(e) in one multiplier (the block scale is static)
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qsc[db][r] = inv_s * osc[db][r] * 1.44269504088896341f;
     if (tI + 1 < tiles && p0 + TP < n) {
       st.begin_tile(stats_b, p0 + TP);
       st.issue(0);
     }
 
+    LSTAMP(0)  // staging + q projection
     // ---- q' = softmax over the 32 d of each pixel column, * scale
     float rsv[4];
 #pragma unroll
@@ -487,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float qv = acc[db][nbn][r] * inv_s * osc[db][r];
+          const float qv = acc[db][nbn][r] * qsc[db][r];   // q * log2(e): the softmax runs in the base-2 domain
           acc[db][nbn][r] = qv;
           m = fmaxf(m, qv);
         }
@@ -497,15 +515,17 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __expf(acc[db][nbn][r] - m);  // hardware exp2: ~1e-7 relative, as in pass 1
+          const float e = __builtin_amdgcn_exp2f(acc[db][nbn][r] - m);  // v_exp_f32: ~1e-7 relative, as in pass 1
           acc[db][nbn][r] = e;
           s += e;
         }
       s = rows_sum(s);
       // one division per pixel column instead of 32 (softmax * scale, CFG:262-263).  * 2^17 (undone in inv_c): q' <= scale
       // < 2^-2 becomes <= 2^15, so the second fp16 piece of every q' that matters is a normal fp16 number
-      rsv[nbn] = scale * 131072.f / s;   // (the split below multiplies: q' = e * rs as two fp16 pieces of the exact product)
+      rsv[nbn] = scale * 131072.f * __builtin_amdgcn_rcpf(s);   // v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division;
+                                                                // the split below multiplies: q' = e * rs as two fp16 pieces
     }
+    LSTAMP(1)  // softmax
     // ---- out^T[e][n] = sum_d ctx[d][e] q'[n][d]
     float4v yacc[4][4];  // FUSE: this head's part of to_out: rows c (cb, 4*kg + r), columns = pixels
     // q' of pixel column l15 (0 <= q' * 2^17 <= 2^15) as fp16 pieces: the lane's 8 values are one K = 32 B-fragment slice
@@ -574,6 +594,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         }
       }
     }
+    LSTAMP(2)  // q' split, ctx product, to_out product
     if (FUSE) {
       // partial sums of the four heads -> LDS [head][pixel][channel]; lane (pixel column l15 of block nbn) holds the four
       // consecutive channels cb*16 + 4*kg .. +3
@@ -594,6 +615,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       }
       const float4 oq = ld4(fo.osc_o + quad * 4), bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
       __syncthreads();
+      LSTAMP(3)  // exchange write + barrier
       // 64 pixels x 16 channel quads: sum the heads, undo the weight scale, + bias, LayerNorm over the 64 channels (two
       // passes, as chan_layernorm_kernel), * g, + x
 #pragma unroll
@@ -612,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
         float qs = (dx * dx + dy * dy) + (dz * dz + dw * dw);
         qs = row16_sum(qs);
-        const float rs = 1.0f / sqrtf(qs / 64.f + fo.eps);
+        const float rs = __builtin_amdgcn_rsqf(qs * (1.f / 64.f) + fo.eps);   // v_rsq_f32 (1 ulp) instead of sqrt + IEEE division
         const int pix = p0 + pl;
         if (pix < n) {
           float4 r4;
@@ -624,9 +646,18 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         }
       }
     }
+    LSTAMP(4)  // LayerNorm + residual + store
     if (FUSE) __syncthreads();  // the exchange buffer is free for the next sub-tile
+    LSTAMP(5)  // end barrier
   }
+#ifdef DMH_STAMPS
+  if (FUSE && lane == 0) {   // diagnostic build only: the counters overwrite the first outputs of the workgroup's first sub-tile
+    float* d = fo.y + ((size_t)b * n + (size_t)blk * tiles * TP) * 64 + h * 8;
+    for (int i = 0; i < 6; ++i) d[i] = (float)tk[i];
+  }
+#endif
 }
+#undef LSTAMP
 
 // ------------------------------------------------------------------------------------------ weight packing
 // to_qkv weight [384][C] (1x1, no bias): rows 0..127 q, 128..255 k, 256..383 v, row = part*128 + head*32 + d.
