@@ -133,6 +133,10 @@ __device__ __forceinline__ void dmh_split8(const float (&x)[8], float s, dmh_hal
   dmh_split2(x[2], x[3], s, hh.y, rr.y);
   dmh_split2(x[4], x[5], s, hh.z, rr.z);
   dmh_split2(x[6], x[7], s, hh.w, rr.w);
+  // The pieces are MFMA operands, and hipcc's hazard recognizer does not see registers written inside inline asm: without
+  // wait states here an MFMA scheduled right behind the split read them before they were written (seen as NaN / a lost
+  // second piece in one 16-pixel block of linattn_qo_kernel, moving with the schedule).
+  asm volatile("s_nop 3" : "+v"(hh.x), "+v"(hh.y), "+v"(hh.z), "+v"(hh.w), "+v"(rr.x), "+v"(rr.y), "+v"(rr.z), "+v"(rr.w));
   h = __builtin_bit_cast(dmh_half8, hh);
   r = __builtin_bit_cast(dmh_half8, rr);
 }
