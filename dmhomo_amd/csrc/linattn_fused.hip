@@ -365,7 +365,6 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
   constexpr int NBUF = FUSE ? 1 : 2;
   unsigned char* tiles_lds = smem;
   float* yx = reinterpret_cast<float*>(smem + TILE_BYTES);  // FUSE only
-  float* hx = reinterpret_cast<float*>(smem + TILE_BYTES + YX_BYTES);  // FUSE only: the four heads' unscale factors
 
   const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -413,10 +412,6 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
     inv_c = __uint_as_float((unsigned)(ex - 14 - 17) << 23);  // 1 / scc, and the 2^17 q' carries (below)
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) dmh_split8(cv[eb], scc, c1[eb], c2[eb]);
-    // FUSE: |ctx^T q'| <= max|ctx| * sum_d q' and sum_d q' * 2^17 = scale * 2^17 < 2^15, so in the scaled units of the two
-    // operands the product stays below 2^30: it is split with the STATIC multiplier 2^-15 (no per-pixel maximum), and this
-    // head's to_out contribution is unscaled by one workgroup-wide constant, applied where the heads are summed
-    if (FUSE && lane == 0) hx[h] = __uint_as_float((unsigned)(ex - 14 - 17 + 15) << 23);
   }
   float* ob = out + (size_t)b * n * 128 + h * 32;
   // FUSE: to_out weight fragments of this head (A operand: rows c, K = the head's 32 channels), kept in registers
@@ -559,37 +554,44 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
 #pragma unroll
       for (int eb = 0; eb < 2; ++eb)
         ot[nbn][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1[eb], q1[nbn], ot[nbn][eb], 0, 0, 0);
-    if (!FUSE) {
 #pragma unroll
-      for (int nbn = 0; nbn < 4; ++nbn) {
+    for (int nbn = 0; nbn < 4; ++nbn) {
+      float4v o[2];
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb) o[eb] = ot[nbn][eb] * inv_c;
+      if (!FUSE) {
         const int pix = p0 + nbn * 16 + l15;  // column = pixel; rows e = eb*16 + 4*kg + r: four consecutive channels
         if (pix < n) {
 #pragma unroll
-          for (int eb = 0; eb < 2; ++eb) {
-            const float4v o = ot[nbn][eb] * inv_c;
-            st4(ob + (size_t)pix * 128 + eb * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
-          }
+          for (int eb = 0; eb < 2; ++eb)
+            st4(ob + (size_t)pix * 128 + eb * 16 + 4 * kg, make_float4(o[eb][0], o[eb][1], o[eb][2], o[eb][3]));
         }
-      }
-    } else {
-      // the 8 values of a lane (e = eb*16 + 4*kg + r of pixel column l15) are one K = 32 B-fragment slice of the to_out
-      // product; static scale (above); per pixel block four independent chains, term by term
+      } else {
+        // the 8 values of this lane (e = eb*16 + 4*kg + r of pixel column l15) are one K = 32 B-fragment slice;
+        // block scale per pixel column (max over the column's 32 e = over the 4 kg lanes), fp16 pieces as everywhere
+        unsigned mx = 0u;
 #pragma unroll
-      for (int nbn = 0; nbn < 4; ++nbn) {
+        for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = max(mx, absbits(o[eb][r]));
+        mx = rows_max_u32(mx);
+        const int ex = min(max((int)(mx >> 23), 16), 254);
+        const float sc = __uint_as_float((unsigned)(268 - ex) << 23), inv = __uint_as_float((unsigned)(ex - 14) << 23);
         half8 h1, h2;
         {
           float o8[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o8[j] = ot[nbn][j >> 2][j & 3];
-          dmh_split8(o8, 1.f / 32768.f, h1, h2);
+          for (int j = 0; j < 8; ++j) o8[j] = o[j >> 2][j & 3];
+          dmh_split8(o8, sc, h1, h2);
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-          yacc[cb][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h2, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) yacc[cb][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo2[cb], h1, yacc[cb][nbn], 0, 0, 0);
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) yacc[cb][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h1, yacc[cb][nbn], 0, 0, 0);
+        for (int cb = 0; cb < 4; ++cb) {
+          float4v t = float4v{0.f, 0.f, 0.f, 0.f};
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h2, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo2[cb], h1, t, 0, 0, 0);
+          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h1, t, 0, 0, 0);
+          yacc[cb][nbn] = t * inv;
+        }
       }
     }
     LSTAMP(2)  // q' split, ctx product, to_out product
@@ -613,12 +615,6 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       }
       const float4 oq = ld4(fo.osc_o + quad * 4), bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
       __syncthreads();
-      float4 wq[4];   // per head: its unscale factor (hx) times the 2^-k of the to_out rows
-#pragma unroll
-      for (int hh = 0; hh < 4; ++hh) {
-        const float f = hx[hh];
-        wq[hh] = make_float4(f * oq.x, f * oq.y, f * oq.z, f * oq.w);
-      }
       LSTAMP(3)  // exchange write + barrier
       // 64 pixels x 16 channel quads: sum the heads, undo the weight scale, + bias, LayerNorm over the 64 channels (two
       // passes, as chan_layernorm_kernel), * g, + x
@@ -628,10 +624,10 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         const float* yp = yx + pl * YP + quad * 4;
         const float4 y0 = ld4(yp), y1 = ld4(yp + TP * YP), y2 = ld4(yp + 2 * TP * YP), y3 = ld4(yp + 3 * TP * YP);
         float4 v;
-        v.x = fmaf(y0.x, wq[0].x, fmaf(y1.x, wq[1].x, fmaf(y2.x, wq[2].x, fmaf(y3.x, wq[3].x, bq4.x))));
-        v.y = fmaf(y0.y, wq[0].y, fmaf(y1.y, wq[1].y, fmaf(y2.y, wq[2].y, fmaf(y3.y, wq[3].y, bq4.y))));
-        v.z = fmaf(y0.z, wq[0].z, fmaf(y1.z, wq[1].z, fmaf(y2.z, wq[2].z, fmaf(y3.z, wq[3].z, bq4.z))));
-        v.w = fmaf(y0.w, wq[0].w, fmaf(y1.w, wq[1].w, fmaf(y2.w, wq[2].w, fmaf(y3.w, wq[3].w, bq4.w))));
+        v.x = fmaf((y0.x + y1.x) + (y2.x + y3.x), oq.x, bq4.x);
+        v.y = fmaf((y0.y + y1.y) + (y2.y + y3.y), oq.y, bq4.y);
+        v.z = fmaf((y0.z + y1.z) + (y2.z + y3.z), oq.z, bq4.z);
+        v.w = fmaf((y0.w + y1.w) + (y2.w + y3.w), oq.w, bq4.w);
         float sm = (v.x + v.y) + (v.z + v.w);
         sm = row16_sum(sm);
         const float mean = sm / 64.f;
@@ -863,7 +859,7 @@ extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, c
   fo.g_out = out_ln_g;
   fo.y = y;
   fo.eps = eps;
-  constexpr int LDS = TILE_BYTES + YX_BYTES + 16;
+  constexpr int LDS = TILE_BYTES + YX_BYTES;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)linattn_qo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

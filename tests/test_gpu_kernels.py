@@ -294,6 +294,24 @@ def test_linear_attention_block_fused(ops, H, W):
     assert torch.isfinite(got).all() and rel < 2e-5, rel
 
 
+def test_linear_attention_block_fused_rows_independent_under_load(ops):
+    """the fused block at 128x128 with 25 samples (800 workgroups: more than the chip holds at once) returns for its first
+    samples bitwise what a launch of those samples alone returns, launch after launch.  (Round 2: a variant that fed MFMA
+    results straight into inline asm passed every parity case and failed exactly this — a timing-dependent read of
+    accumulators the matrix core had not written yet, a few pixels per launch, only with two workgroups per CU.)"""
+    C, H, W = 64, 128, 128
+    g = (1 + 0.2 * rand((C,), 51)).to(dev())
+    pla = ops.PackedLinAttn(rand((384, C, 1, 1), 52, C ** -0.5).to(dev()))
+    plo = ops.PackedLinAttnOut((rand((C, 128, 1, 1), 53, 128 ** -0.5) * 30.0).to(dev()), rand((C,), 54, 0.1).to(dev()),
+                               (1 + 0.2 * rand((C,), 55)).to(dev()))
+    x = (rand((25, H, W, C), 50) * 1.3 + 0.2).to(dev())
+    alone = ops.linear_attention_fused(x[:2].contiguous(), g, pla, 32 ** -0.5, out=plo)
+    core = ops.linear_attention_fused(x[:2].contiguous(), g, pla, 32 ** -0.5)
+    for _ in range(3):
+        assert torch.equal(ops.linear_attention_fused(x, g, pla, 32 ** -0.5, out=plo)[:2], alone)
+        assert torch.equal(ops.linear_attention_fused(x, g, pla, 32 ** -0.5)[:2], core)
+
+
 def test_linear_attention_uniform_k_gives_mean_v(ops):
     """known answer: constant k -> softmax_n uniform -> ctx[d][e] = mean_n(v[e]) / n for every d (v is scaled by 1/n)"""
     H = W = 12

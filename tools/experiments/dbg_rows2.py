@@ -1,0 +1,37 @@
+import sys, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import torch.nn.functional as F
+from gpu_util import rand
+from dmhomo_amd import ops
+dev = torch.device('cuda', 0)
+C, B, H, W = 64, 25, 128, 128
+x = (rand((B, H, W, C), 50) * 1.3 + 0.2)
+g = 1 + 0.2 * rand((C,), 51)
+w = rand((384, C, 1, 1), 52, C ** -0.5)
+wo = rand((C, 128, 1, 1), 53, 128 ** -0.5) * 30.0
+bo = rand((C,), 54, 0.1)
+go = 1 + 0.2 * rand((C,), 55)
+pla = ops.PackedLinAttn(w.to(dev))
+plo = ops.PackedLinAttnOut(wo.to(dev), bo.to(dev), go.to(dev))
+xd = x.to(dev)
+yb = ops.linear_attention_fused(xd, g.to(dev), pla, 32 ** -0.5, out=plo)[:2].cpu().double()
+y2 = ops.linear_attention_fused(xd[:2].contiguous(), g.to(dev), pla, 32 ** -0.5, out=plo).cpu().double()
+# fp64 reference for the first two samples
+xs = x[:2].permute(0, 3, 1, 2).double()
+def ln(t, gain):
+    m = t.mean(1, keepdim=True); v = t.var(1, unbiased=False, keepdim=True)
+    return (t - m) / (v + 1e-5).sqrt() * gain.double()[None, :, None, None]
+qkv = F.conv2d(ln(xs, g), w.double())
+n = H * W
+q, k, v = [t.reshape(2, 4, 32, n) for t in qkv.chunk(3, dim=1)]
+q = q.softmax(dim=-2) * 32 ** -0.5
+k = k.softmax(dim=-1)
+ctx = torch.einsum('b h d n, b h e n -> b h d e', k, v / n)
+core = torch.einsum('b h d e, b h d n -> b h e n', ctx, q).reshape(2, 128, H, W)
+ref = (xs + ln(F.conv2d(core, wo.double(), bo.double()), go)).permute(0, 2, 3, 1)
+for name, y in (('rows of the 25-sample launch', yb), ('the same 2 rows alone', y2)):
+    e = (y - ref).abs()
+    print(name, 'max err', float(e.max()), 'rel', float(e.max() / ref.abs().max()), 'pixels with err > 1e-5:', int((e.amax(-1) > 1e-5).sum()))
+d = (yb - y2).abs().amax(-1)
+idx = (d > 1e-6).nonzero()
+print('differing pixels', idx.shape[0], idx[:8].tolist())
