@@ -158,6 +158,33 @@ def test_conv2d_prologue_and_residual(ops):
           rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('name,C0,C1,Co,H,k', [('3x3 64->64 @128', 64, 0, 64, 128, 3), ('3x3 64+64->64 @128', 64, 64, 64, 128, 3),
+                                               ('3x3 512->512 @16', 512, 0, 512, 16, 3), ('1x1 64+64->64 @128', 64, 64, 64, 128, 1)])
+def test_conv2d_rows_independent_under_load(ops, name, C0, C1, Co, H, k):
+    """a 50-row launch (more workgroups than the chip holds at once, two per CU) returns for its first rows — outputs and
+    GroupNorm partials — bitwise what a launch of those rows alone returns, launch after launch: nothing in the kernel may
+    depend on timing or on which other workgroups share the CU"""
+    B = 50
+    w = rand((Co, C0 + C1, k, k), 1, (1.0 / ((C0 + C1) * k * k)) ** 0.5).to(dev())
+    pc = ops.PackedConv(w, rand((Co,), 2, 0.1).to(dev()), C0, C1)
+    x0 = rand((B, H, H, C0), 3).to(dev())
+    x1 = rand((B, H, H, C1), 4).to(dev()) if C1 else None
+    coef = None
+    if C1 == 0 and k == 3:
+        coef = torch.stack([1 + 0.1 * rand((B, C0), 5), 0.1 * rand((B, C0), 6)], 1).contiguous().to(dev())
+    res = rand((B, H, H, Co), 7).to(dev())
+
+    def run(n):
+        o = ops.conv2d(pc, x0[:n].contiguous(), None if x1 is None else x1[:n].contiguous(),
+                       in_coef=None if coef is None else coef[:n].contiguous(), res=res[:n].contiguous(), want_stats=(k == 3))
+        return o if isinstance(o, tuple) else (o, None)
+    a, sa = run(2)
+    for _ in range(3):
+        b, sb = run(B)
+        assert torch.equal(b[:2], a)
+        assert sa is None or torch.equal(sb[:2], sa)
+
+
 def test_conv2d_rejects_bad_channels(ops):
     from dmhomo_amd._lib import DmhError
     pc = ops.PackedConv(rand((8, 6, 3, 3), 1).to(dev()), None, 6)
