@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Scan gfx950 assembly (hipcc -S --cuda-device-only) for hazards hipcc's recognizer cannot see because one side is inline asm.
+
+Inline asm shows up between ;;#ASMSTART / ;;#ASMEND.  For every VALU instruction inside such a block report, within WINDOW
+preceding instructions:
+  RAW   a source register written by an MFMA (vDst)
+  WAW   the destination written by an MFMA
+  WAR-C the destination read as SrcC by an MFMA whose vDst is a different register range
+and for every MFMA: A/B/C sources written by an inline-asm VALU less than NOPS wait states earlier.
+"""
+import re, sys
+WINDOW = 19   # the longest wait the gfx950 tables ask for (16-pass MFMA result -> VALU)
+def regs(tok):
+    tok = tok.strip().rstrip(',')
+    m = re.match(r'-?\|?v\[(\d+):(\d+)\]', tok)
+    if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r'-?\|?v(\d+)\b', tok)
+    if m: return {int(m.group(1))}
+    return set()
+def scan(path):
+    kern = None; hist = []; in_asm = False; n_find = 0
+    for ln, line in enumerate(open(path), 1):
+        s = line.strip()
+        if s.endswith(':') and not s.startswith(';') and not s.startswith('.L'):
+            kern = s[:-1]; hist = []; continue
+        if s.startswith(';;#ASMSTART'): in_asm = True; continue
+        if s.startswith(';;#ASMEND'): in_asm = False; continue
+        if not s or s[0] in ';.': continue
+        body = s.split(';')[0].strip()
+        parts = body.split(None, 1)
+        op = parts[0]; ops = parts[1].split(',') if len(parts) > 1 else []
+        ops = [o.strip() for o in ops]
+        waits = 1
+        if op == 's_nop': waits = int(ops[0]) + 1
+        if op.startswith('v_mfma'):
+            d, a, b, c = regs(ops[0]), regs(ops[1]), regs(ops[2]), regs(ops[3])
+            # producers in asm
+            dist = 0
+            for h in reversed(hist):
+                if h['asm'] and h['dst'] & (a | b | c) and dist < 4:
+                    print(f'{kern}:{ln}: MFMA reads v{sorted(h["dst"] & (a|b|c))} written by inline asm {dist} wait states earlier (line {h["ln"]})'); n_find += 1
+                dist += h['waits']
+                if dist > WINDOW: break
+            hist.append(dict(kind='mfma', dst=d, c=c, asm=False, ln=ln, waits=1))
+        elif in_asm and op.startswith('v_'):
+            d = regs(ops[0]); srcs = set()
+            for o in ops[1:]: srcs |= regs(o)
+            if 'mixhi' in op or 'mixlo' in op: srcs |= d
+            dist = 0
+            for h in reversed(hist):
+                if h['kind'] == 'mfma':
+                    if h['dst'] & srcs: print(f'{kern}:{ln}: asm {op} RAW on MFMA vDst v{sorted(h["dst"] & srcs)} ({dist} wait states, mfma line {h["ln"]})'); n_find += 1
+                    if h['dst'] & d: print(f'{kern}:{ln}: asm {op} WAW on MFMA vDst v{sorted(h["dst"] & d)} ({dist} wait states, mfma line {h["ln"]})'); n_find += 1
+                    if h['c'] & d and h['c'] != h['dst']: print(f'{kern}:{ln}: asm {op} WAR on MFMA SrcC v{sorted(h["c"] & d)} ({dist} wait states, mfma line {h["ln"]})'); n_find += 1
+                dist += h['waits']
+                if dist > WINDOW: break
+            hist.append(dict(kind='valu', dst=d, asm=True, ln=ln, waits=1))
+        else:
+            d = regs(ops[0]) if ops and op.startswith(('v_', 'ds_read', 'global_load', 'buffer_load')) else set()
+            hist.append(dict(kind='other', dst=d, asm=False, ln=ln, waits=waits))
+        if len(hist) > 4 * WINDOW: hist = hist[-2 * WINDOW:]
+    return n_find
+if __name__ == '__main__':
+    tot = sum(scan(p) for p in sys.argv[1:])
+    print('findings:', tot)
