@@ -122,11 +122,11 @@ struct EpilogueRows {
   bool okr[8];
   float4 rv[8];
   bool pre = false;
-  template <int TW>
+  template <int TW, int NR = 8>
   __device__ __forceinline__ void prefetch_rows(const ConvArgs& p, int row_base, int oy0, int ox0, int mul = 1, int dy = 0,
                                                 int dx = 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int row = row_base + i * 4 + rsub;
       const int oy = (oy0 + row / TW) * mul + dy, ox = (ox0 + row % TW) * mul + dx;
       okr[i] = cok && oy < p.Hout && ox < p.Wout;
@@ -135,24 +135,24 @@ struct EpilogueRows {
     }
     if (p.res) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) rv[i] = ld4(p.res + oo[i]);
+      for (int i = 0; i < NR; ++i) rv[i] = ld4(p.res + oo[i]);
     }
     pre = true;
   }
 
-  template <int TW, typename Fetch>
+  template <int TW, int NR = 8, typename Fetch>
   __device__ __forceinline__ void store_rows_fn(const ConvArgs& p, Fetch fetch, int row_base, int oy0, int ox0,
                                                 int mul = 1, int dy = 0, int dx = 0) {
-    if (!pre) prefetch_rows<TW>(p, row_base, oy0, ox0, mul, dy, dx);
+    if (!pre) prefetch_rows<TW, NR>(p, row_base, oy0, ox0, mul, dy, dx);
     pre = false;
     // all 8 rows are fetched and finished on every lane; only the store and the GroupNorm partials look at the row's
     // validity (round 1 wrapped each row in its own exec-masked region, which pinned every slab read behind the previous
     // row's store)
     float4 val[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) val[i] = fetch(i * 4 + rsub);
+    for (int i = 0; i < NR; ++i) val[i] = fetch(i * 4 + rsub);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NR; ++i) {
       val[i].x = fmaf(val[i].x, osc.x, bias.x);  // osc == 1 unless the kernel scaled its weights: then exactly val + bias
       val[i].y = fmaf(val[i].y, osc.y, bias.y);
       val[i].z = fmaf(val[i].z, osc.z, bias.z);
@@ -161,7 +161,7 @@ struct EpilogueRows {
     if (p.res) {
       if (p.res_coef) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NR; ++i) {
           val[i].x += silu_fast(fmaf(ra.x, rv[i].x, rb.x));
           val[i].y += silu_fast(fmaf(ra.y, rv[i].y, rb.y));
           val[i].z += silu_fast(fmaf(ra.z, rv[i].z, rb.z));
@@ -169,7 +169,7 @@ struct EpilogueRows {
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NR; ++i) {
           val[i].x += rv[i].x;
           val[i].y += rv[i].y;
           val[i].z += rv[i].z;
@@ -178,7 +178,7 @@ struct EpilogueRows {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NR; ++i) {
       if (okr[i]) st4(p.out + oo[i], val[i]);
       const float k = okr[i] ? 1.f : 0.f;     // rows outside the image do not enter the statistics
       const float vx = val[i].x * k, vy = val[i].y * k, vz = val[i].z * k, vw = val[i].w * k;
