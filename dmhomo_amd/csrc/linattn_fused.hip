@@ -215,19 +215,33 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
     }
 
     // ---- k, v of this sub-tile: acc[mb][nb][r] = value(pixel p0 + mb*16 + 4*kg + r, column nb*16 + l15)
+    // (1 / block scale and the weight column's 2^-k are both powers of two: one exact multiplier)
+    const bool full = p0 + TP <= n;  // uniform: only the last sub-tile of a ragged image masks its pixels
     float m_new[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
+      const float kk = inv_s * osc[db];
       float m = -INFINITY;
+      if (full) {
 #pragma unroll
-      for (int mb = 0; mb < 4; ++mb)
+        for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool valid = p0 + mb * 16 + 4 * kg + r < n;
-          const float kv = valid ? acc[mb][db][r] * inv_s * osc[db] : -INFINITY;
-          acc[mb][db][r] = kv;
-          m = fmaxf(m, kv);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const float kv = acc[mb][db][r] * kk;
+            acc[mb][db][r] = kv;
+            m = fmaxf(m, kv);
+          }
+      } else {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool valid = p0 + mb * 16 + 4 * kg + r < n;
+            const float kv = valid ? acc[mb][db][r] * kk : -INFINITY;
+            acc[mb][db][r] = kv;
+            m = fmaxf(m, kv);
+          }
+      }
       m = rows_max(m);
       m_new[db] = fmaxf(m_run[db], m);
     }
@@ -269,13 +283,14 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
     float inv_v[2];
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
+      // (pixels beyond n were staged as zeros, so their v is exactly 0 without a mask)
+      const float kv2 = inv_s * osc[2 + eb];
       unsigned mx = 0u;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool valid = p0 + mb * 16 + 4 * kg + r < n;
-          const float vv = valid ? acc[mb][2 + eb][r] * inv_s * osc[2 + eb] : 0.f;
+          const float vv = acc[mb][2 + eb][r] * kv2;
           acc[mb][2 + eb][r] = vv;
           mx = max(mx, absbits(vv));
         }
