@@ -46,6 +46,7 @@ SIGNATURES = {
     'dmh_gn_finalize': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int,
                                 c_float, C.c_void_p]),
     'dmh_gn_silu_residual': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_gn_silu_residual_stats': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, C.c_void_p]),
     'dmh_chan_layernorm': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),
     'dmh_linattn_splits': (c_int, [c_int]),
     'dmh_linattn_partial_floats': (c_i64, [c_int, c_int]),

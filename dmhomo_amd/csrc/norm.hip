@@ -61,12 +61,22 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // out = SiLU(a*y + b) + res, elementwise NHWC, a/b per (sample, channel)
+// LPP > 0 (= C / 4 lanes per pixel): also the per-pixel (mean, rstd) of the channel LayerNorm of `out`, for the fused
+// LinearAttention that follows a ResnetBlock (CFG:176-183 after :241) — the lanes of a pixel and the order of the sums are
+// those of pixel_stats_kernel<LPP, 1>, so the values are bitwise the ones that kernel would compute from `out`, without
+// reading it again.  Every lane of a wave runs every iteration (clamped index, guarded store): the lane sums need them all.
+template <int LPP>
 __global__ __launch_bounds__(256) void gn_silu_residual_kernel(const float* __restrict__ y,
                                                                const float* __restrict__ coef,
                                                                const float* __restrict__ res, float* __restrict__ out,
-                                                               int64_t per_sample4, int C, int64_t total4) {
+                                                               int64_t per_sample4, int C, int64_t total4,
+                                                               float* __restrict__ pstats, float eps) {
   const int C4 = C >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 - lane < total4; i0 += (int64_t)gridDim.x * 256) {
+    const bool ok = i0 < total4;
+    if (LPP == 0 && !ok) break;
+    const int64_t i = ok ? i0 : total4 - 1;
     const int b = (int)(i / per_sample4);
     const int c = (int)(i % C4) * 4;
     const float4 a = ld4(coef + (size_t)(b * 2 + 0) * C + c);
@@ -79,7 +89,22 @@ __global__ __launch_bounds__(256) void gn_silu_residual_kernel(const float* __re
     o.y = silu_fast(fmaf(a.y, v.y, bb.y)) + r.y;
     o.z = silu_fast(fmaf(a.z, v.z, bb.z)) + r.z;
     o.w = silu_fast(fmaf(a.w, v.w, bb.w)) + r.w;
-    st4(out + i * 4, o);
+    if (ok) st4(out + i * 4, o);
+    if (LPP > 0) {
+      float s = 0.f;
+      s += (o.x + o.y) + (o.z + o.w);
+      s = lanes_sum<(LPP > 0 ? LPP : 1)>(s);
+      const float mean = s / (float)C;
+      float qsum = 0.f;
+      const float dx = o.x - mean, dy = o.y - mean, dz = o.z - mean, dw = o.w - mean;
+      qsum += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      qsum = lanes_sum<(LPP > 0 ? LPP : 1)>(qsum);
+      if (ok && (threadIdx.x % (LPP > 0 ? LPP : 1)) == 0) {
+        const int64_t pix = i / C4;
+        pstats[pix * 2 + 0] = mean;
+        pstats[pix * 2 + 1] = 1.0f / sqrtf(qsum / (float)C + eps);
+      }
+    }
   }
 }
 
@@ -169,9 +194,32 @@ extern "C" int dmh_gn_silu_residual(const float* y, const float* coef, const flo
   const int64_t per_sample4 = (int64_t)HW * C / 4;
   const int64_t total4 = per_sample4 * B;
   const unsigned grid = (unsigned)(cdiv64(total4, 256) < 8192 ? cdiv64(total4, 256) : 8192);
-  hipLaunchKernelGGL(gn_silu_residual_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, coef, res, out,
-                     per_sample4, C, total4);
+  hipLaunchKernelGGL(gn_silu_residual_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, coef, res, out,
+                     per_sample4, C, total4, (float*)nullptr, 0.f);
   DMH_CHECK_LAUNCH("dmh_gn_silu_residual");
+  return DMH_OK;
+}
+
+// same + pstats [B*HW][2] = (mean, rstd) over the channels of every output pixel, as dmh_pixel_stats(out) would give
+extern "C" int dmh_gn_silu_residual_stats(const float* y, const float* coef, const float* res, float* out, float* pstats,
+                                          int B, int HW, int C, float eps, void* stream) {
+  DMH_REQUIRE(y && coef && out && pstats, "dmh_gn_silu_residual_stats: null pointer");
+  DMH_REQUIRE(B > 0 && HW > 0 && (C == 64 || C == 128 || C == 256),
+              "dmh_gn_silu_residual_stats: C must be 64, 128 or 256 (got %d)", C);
+  const int64_t per_sample4 = (int64_t)HW * C / 4;
+  const int64_t total4 = per_sample4 * B;
+  const unsigned grid = (unsigned)(cdiv64(total4, 256) < 8192 ? cdiv64(total4, 256) : 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (C == 64)
+    hipLaunchKernelGGL(gn_silu_residual_kernel<16>, dim3(grid), dim3(256), 0, st, y, coef, res, out, per_sample4, C, total4,
+                       pstats, eps);
+  else if (C == 128)
+    hipLaunchKernelGGL(gn_silu_residual_kernel<32>, dim3(grid), dim3(256), 0, st, y, coef, res, out, per_sample4, C, total4,
+                       pstats, eps);
+  else
+    hipLaunchKernelGGL(gn_silu_residual_kernel<64>, dim3(grid), dim3(256), 0, st, y, coef, res, out, per_sample4, C, total4,
+                       pstats, eps);
+  DMH_CHECK_LAUNCH("dmh_gn_silu_residual_stats");
   return DMH_OK;
 }
 

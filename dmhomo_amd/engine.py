@@ -183,7 +183,9 @@ class UnetEngine:
         self.mlp_b = torch.cat(mlp_b).contiguous()
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, r, x0, x1, ss_all):
+    def _res(self, r, x0, x1, ss_all, pixel_stats=False):
+        """pixel_stats: return (x, stats) with the channel-LayerNorm statistics of x for the LinearAttention that
+        follows (None where the block's last kernel cannot produce them)."""
         B, H, W, _ = x0.shape
         hw = H * W
         y1, st1 = ops.conv2d(r.conv1, x0, x1, want_stats=True)
@@ -192,15 +194,20 @@ class UnetEngine:
         y2, st2 = ops.conv2d(r.conv2, y1, in_coef=coef1, want_stats=True)
         coef2 = ops.gn_finalize(st2, r.g2, r.b2, hw, self.groups)
         if r.res is not None:
-            return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2)
+            x = ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2)
+            return (x, None) if pixel_stats else x
         assert x1 is None
+        if pixel_stats:
+            if r.cout in ops.PIXEL_STATS_FUSABLE:
+                return ops.gn_silu_residual(y2, coef2, x0, pixel_stats=True)
+            return ops.gn_silu_residual(y2, coef2, x0), None
         return ops.gn_silu_residual(y2, coef2, x0)
 
-    def _attn(self, a, x):
+    def _attn(self, a, x, stats=None):
         if a.plo is not None:
-            return ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, out=a.plo)
+            return ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, out=a.plo, stats=stats)
         if a.pla is not None:
-            o = ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE)
+            o = ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, stats=stats)
             y = ops.conv2d(a.out, o)
             return ops.chan_layernorm(y, a.out_g, res=x)
         xn = ops.chan_layernorm(x, a.ln_g)
@@ -251,8 +258,10 @@ class UnetEngine:
         for i, (b1, b2, at, down) in enumerate(self.downs):
             x = tap(f'downs.{i}.0', self._res(b1, x, None, ss_all))
             hs.append(x)
-            x = tap(f'downs.{i}.1', self._res(b2, x, None, ss_all))
-            x = tap(f'downs.{i}.2', self._attn(at, x))
+            x, pst = self._res(b2, x, None, ss_all, pixel_stats=True) if at.pla is not None else \
+                (self._res(b2, x, None, ss_all), None)
+            tap(f'downs.{i}.1', x)
+            x = tap(f'downs.{i}.2', self._attn(at, x, pst))
             hs.append(x)
             x = tap(f'downs.{i}.3', ops.conv2d(down, x))
         x = tap('mid_block1', self._res(self.mid1, x, None, ss_all))
@@ -260,8 +269,10 @@ class UnetEngine:
         x = tap('mid_block2', self._res(self.mid2, x, None, ss_all))
         for i, (b1, b2, at, up) in enumerate(self.ups):
             x = tap(f'ups.{i}.0', self._res(b1, x, hs.pop(), ss_all))
-            x = tap(f'ups.{i}.1', self._res(b2, x, hs.pop(), ss_all))
-            x = tap(f'ups.{i}.2', self._attn(at, x))
+            x, pst = self._res(b2, x, hs.pop(), ss_all, pixel_stats=True) if at.pla is not None else \
+                (self._res(b2, x, hs.pop(), ss_all), None)
+            tap(f'ups.{i}.1', x)
+            x = tap(f'ups.{i}.2', self._attn(at, x, pst))
             x = tap(f'ups.{i}.3', ops.conv2d(up, x))
         x = tap('final_res_block', self._res(self.final_res, x, r, ss_all))
         return ops.final_conv_nchw(x, self.final_w, self.final_b)

@@ -6,6 +6,8 @@ are NHWC fp32 tensors shaped (B, H, W, C).
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -105,9 +107,20 @@ def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5):
     return coef
 
 
-def gn_silu_residual(y, coef, res):
+# widths whose ResnetBlock epilogue can hand the LayerNorm statistics to the LinearAttention behind it
+# (development knob DMH_FUSED_PIXEL_STATS=0: the standalone dmh_pixel_stats pass everywhere, for A/B runs)
+PIXEL_STATS_FUSABLE = () if os.environ.get('DMH_FUSED_PIXEL_STATS') == '0' else (64, 128, 256)
+
+
+def gn_silu_residual(y, coef, res, pixel_stats=False, eps=1e-5):
+    """SiLU(a*y+b) + res.  pixel_stats: also return the (B, H*W, 2) per-pixel (mean, rstd) of the channel LayerNorm of the
+    result — what ``dmh_pixel_stats`` would compute from it — for ``linear_attention_fused(..., stats=)``."""
     B, H, W, Cc = y.shape
     out = torch.empty_like(y)
+    if pixel_stats:
+        stats = _empty((B, H * W, 2), y)
+        call('dmh_gn_silu_residual_stats', ptr(y), ptr(coef), ptr(res), ptr(out), ptr(stats), B, H * W, Cc, float(eps))
+        return out, stats
     call('dmh_gn_silu_residual', ptr(y), ptr(coef), ptr(res), ptr(out), B, H * W, Cc)
     return out
 
@@ -160,7 +173,7 @@ class PackedLinAttnOut:
         self.ln_g = ln_g.detach().reshape(-1).contiguous().float()
 
 
-def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None):
+def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None):
     """K3f.  x (B,H,W,C) -> attention core output (B,H,W,128) of LinearAttention(PreNorm-LayerNorm(x)): LayerNorm,
     to_qkv and both attention passes in two kernels, q/k/v never stored.
     With ``out`` (PackedLinAttnOut, C == 64) the second pass also applies to_out, its LayerNorm and the residual:
@@ -168,8 +181,10 @@ def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None):
     B, H, W, c = x.shape
     assert c == pla.c
     n = H * W
-    stats = _empty((B, n, 2), x)
-    call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, c, float(eps))
+    if stats is None:     # (the producer of x may have written them already: gn_silu_residual(pixel_stats=True))
+        stats = _empty((B, n, 2), x)
+        call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, c, float(eps))
+    assert stats.shape == (B, n, 2)
     ns = lib().dmh_linattn_fused_splits(B, n)
     partial = _empty((B, ns, 4, 1088), x)
     ctx = _empty((B, 4, 32, 32), x)

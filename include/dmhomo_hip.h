@@ -111,6 +111,11 @@ int dmh_gn_finalize(const float* stats, int tiles, const float* gamma, const flo
 int dmh_gn_silu_residual(const float* y, const float* coef, const float* res, float* out, int B, int HW, int C,
                          void* stream);
 
+/* same, also writing pstats [B*HW][2] = (mean, rstd) of the channel LayerNorm (CFG:137-141) of every output pixel —
+ * bitwise what dmh_pixel_stats(out) gives — for a LinearAttention that follows the block (CFG:176-183). C in {64,128,256}. */
+int dmh_gn_silu_residual_stats(const float* y, const float* coef, const float* res, float* out, float* pstats, int B,
+                               int HW, int C, float eps, void* stream);
+
 /* N4  channel LayerNorm (biased var, gain only), CFG:137-141, optionally + res (Residual, CFG:103) */
 int dmh_chan_layernorm(const float* x, const float* g, const float* res, float* out, int64_t npix, int C,
                        float eps, void* stream);

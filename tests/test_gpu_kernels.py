@@ -219,6 +219,31 @@ def test_block_gn_silu(ops, C, H, W):
     close(f'block C={C}', nchw(ops.gn_silu_residual(y, coef0, None)), ref0, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('C,H,W,B', [(64, 16, 16, 3), (64, 6, 6, 1), (128, 8, 8, 2), (128, 5, 7, 3), (256, 4, 4, 2), (256, 3, 3, 1)])
+def test_gn_silu_residual_pixel_stats_bitwise(ops, C, H, W, B):
+    """the per-pixel LayerNorm statistics a ResnetBlock's last kernel hands to the LinearAttention behind it are bitwise the
+    ones dmh_pixel_stats computes from the block's output (ragged sizes: partially filled waves at the end of the tensor)"""
+    y = rand((B, H, W, C), 41).to(dev())
+    res = rand((B, H, W, C), 42).to(dev())
+    coef = torch.stack([1 + 0.2 * rand((B, C), 43), 0.3 * rand((B, C), 44)], 1).contiguous().to(dev())
+    plain = ops.gn_silu_residual(y, coef, res)
+    out, stats = ops.gn_silu_residual(y, coef, res, pixel_stats=True)
+    assert torch.equal(out, plain)
+    ref = torch.empty((B, H * W, 2), device=dev())
+    from dmhomo_amd._lib import call, ptr
+    call('dmh_pixel_stats', ptr(out), ptr(ref), B * H * W, C, 1e-5)
+    assert torch.equal(stats, ref)
+    mean = out.reshape(B, H * W, C).double().mean(-1)
+    close('pixel mean', stats[..., 0].cpu().double(), mean.cpu(), rtol=1e-5, atol=1e-6)
+
+
+def test_gn_silu_residual_pixel_stats_rejects_other_widths(ops):
+    y = torch.zeros((1, 4, 4, 32), device=dev())
+    coef = torch.zeros((1, 2, 32), device=dev())
+    with pytest.raises(RuntimeError):
+        ops.gn_silu_residual(y, coef, None, pixel_stats=True)
+
+
 def test_gn_constant_input_is_beta(ops):
     """known answer: GroupNorm of a constant tensor = beta (variance 0 -> (x-mean) = 0)"""
     B, C, H, W = 1, 16, 8, 8
