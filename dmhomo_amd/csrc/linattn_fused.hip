@@ -152,7 +152,9 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) osc[nb] = oscale[(h * 4 + nb) * 16 + l15];
 
-  // running state over the sub-tiles: per column d = db*16 + l15 (lanes), ctx blocks [db][eb] (rows d, cols e)
+  // running state over the sub-tiles: per column d = db*16 + l15 (lanes; the maxima in the base-2 domain), and the context
+  // TRANSPOSED, ctx[eb][db] = block (rows e = eb*16 + 4*kg + r, columns d = db*16 + l15): the softmax rescale of a column d
+  // is then one multiplier per lane (round 2, late; with rows d it took eight cross-lane reads per sub-tile)
   float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
   float4v ctx[2][2];
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
     float m_new[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      const float kk = inv_s * osc[db];
+      const float kk = inv_s * osc[db] * 1.44269504088896341f;   // k * log2(e): the softmax runs in the base-2 domain
       float m = -INFINITY;
       if (full) {
 #pragma unroll
@@ -245,24 +247,20 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
       m = rows_max(m);
       m_new[db] = fmaxf(m_run[db], m);
     }
-    // rescale the running context rows by exp(m_run - m_new): rows live in (kg, r), the factor in lane l15 = row
+    // rescale the running context columns by 2^(m_run - m_new): column d = this lane
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      const float fcol = __expf(m_run[db] - m_new[db]);  // 0 on the first sub-tile (m_run = -inf)
+      const float fcol = __builtin_amdgcn_exp2f(m_run[db] - m_new[db]);  // 0 on the first sub-tile (m_run = -inf)
       s_run[db] *= fcol;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float frow = __shfl(fcol, 4 * kg + r);
-        ctx[db][0][r] *= frow;
-        ctx[db][1][r] *= frow;
-      }
+      ctx[0][db] *= fcol;
+      ctx[1][db] *= fcol;
       m_run[db] = m_new[db];
     }
     // ---- ctx[d][e] += sum_n p[n][d] v[n][e] on the fp16 matrix cores (round 2; round 1: 64 fp32 16x16x4 MFMAs per sub-tile,
     // which execute on the vector ALUs).  The accumulator layout is the operand layout: lane (l15, kg) holds column l15
     // (d for p, e for v) of the pixels mb*16 + 4*kg + r, and K slot 8*kg + j of step s is pixel (2s + (j >> 2))*16 + 4*kg
-    // + (j & 3) for A and B alike.  p = exp(k - m) lies in [0, 1]: * 2^10, split; v: per column (= per lane) power-of-two
-    // scale from the column's maximum over the sub-tile, split; the product is unscaled per lane (D columns = e = l15).
+    // + (j & 3) for A and B alike.  p = 2^(k - m) lies in [0, 1]: * 2^10, split; v: one power-of-two scale per wave and
+    // sub-tile, split.  v is the A operand: D rows = e, D columns = d = l15 (the transposed context, see above).
     half8 p1[2][2], p2[2][2], v1[2][2], v2[2][2];  // [block][K step]
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
@@ -272,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
         float pv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          pv[j] = __expf(acc[2 * ks + (j >> 2)][db][j & 3] - m_new[db]);  // exp(-inf) = 0 for pixels beyond n
+          pv[j] = __builtin_amdgcn_exp2f(acc[2 * ks + (j >> 2)][db][j & 3] - m_new[db]);  // 2^-inf = 0 for pixels beyond n
           s += pv[j];
         }
         dmh_split8(pv, 1024.f, p1[db][ks], p2[db][ks]);
@@ -280,12 +278,13 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
       s = rows_sum(s);
       s_run[db] += s;
     }
-    float inv_v[2];
+    // v: one power-of-two scale for the wave's 64 pixels x 32 columns (fp16 pieces are floating point: a block-wide
+    // scale costs range, not precision — as in the conv kernels), so the product is unscaled by one uniform factor
+    unsigned mx = 0u;
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) {
       // (pixels beyond n were staged as zeros, so their v is exactly 0 without a mask)
       const float kv2 = inv_s * osc[2 + eb];
-      unsigned mx = 0u;
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -294,10 +293,13 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
           acc[mb][2 + eb][r] = vv;
           mx = max(mx, absbits(vv));
         }
-      mx = rows_max_u32(mx);
-      const int ex = min(max((int)(mx >> 23), 32), 254);
-      const float scv = __uint_as_float((unsigned)(268 - ex) << 23);      // column maximum * scv in [2^14, 2^15)
-      inv_v[eb] = __uint_as_float((unsigned)(ex - 14 - 10) << 23);        // 1 / scv, and the 2^10 of p
+    }
+    mx = wave_max_u32(mx);
+    const int exv = min(max((int)(mx >> 23), 32), 254);
+    const float scv = __uint_as_float((unsigned)(268 - exv) << 23);         // block maximum * scv in [2^14, 2^15)
+    const float inv_v = __uint_as_float((unsigned)(exv - 14 - 10) << 23);   // 1 / scv, and the 2^10 of p
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         float vv[8];
@@ -305,51 +307,51 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
         for (int j = 0; j < 8; ++j) vv[j] = acc[2 * ks + (j >> 2)][2 + eb][j & 3];
         dmh_split8(vv, scv, v1[eb][ks], v2[eb][ks]);
       }
-    }
-    float4v t[2][2];  // four independent chains, term by term
+    float4v t[2][2];  // [eb][db]: four independent chains, term by term; A = v (rows e), B = p (columns d)
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+        t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2[eb][0], p1[db][0], float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2[eb][1], p1[db][1], t[eb][db], 0, 0, 0);
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2)
 #pragma unroll
       for (int eb = 0; eb < 2; ++eb)
-        t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1[db][0], v2[eb][0], float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int eb = 0; eb < 2; ++eb) t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1[db][1], v2[eb][1], t[db][eb], 0, 0, 0);
+        for (int db = 0; db < 2; ++db)
+          t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1[eb][st2], p2[db][st2], t[eb][db], 0, 0, 0);
 #pragma unroll
     for (int st2 = 0; st2 < 2; ++st2)
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+      for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
-        for (int eb = 0; eb < 2; ++eb)
-          t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p2[db][st2], v1[eb][st2], t[db][eb], 0, 0, 0);
+        for (int db = 0; db < 2; ++db)
+          t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1[eb][st2], p1[db][st2], t[eb][db], 0, 0, 0);
 #pragma unroll
-    for (int st2 = 0; st2 < 2; ++st2)
+    for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int eb = 0; eb < 2; ++eb)
-          t[db][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1[db][st2], v1[eb][st2], t[db][eb], 0, 0, 0);
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int eb = 0; eb < 2; ++eb) ctx[db][eb] += t[db][eb] * inv_v[eb];
+      for (int db = 0; db < 2; ++db) ctx[eb][db] += t[eb][db] * inv_v;
   }
 
   float* out = partial + ((size_t)(b * nsplit + sp) * 4 + h) * LA_PART;
   if (kg == 0) {
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
-      out[db * 16 + l15] = m_run[db];
+      out[db * 16 + l15] = m_run[db] * 0.693147180559945309f;   // back to the natural domain the merge works in
       out[32 + db * 16 + l15] = s_run[db];
     }
   }
+  // ctx[d][e] row-major: this lane's four consecutive e of column d are one 16 B piece
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) out[64 + (db * 16 + 4 * kg + r) * 32 + eb * 16 + l15] = ctx[db][eb][r];
+      st4(out + 64 + (db * 16 + l15) * 32 + eb * 16 + 4 * kg,
+          make_float4(ctx[eb][db][0], ctx[eb][db][1], ctx[eb][db][2], ctx[eb][db][3]));
 }
 
 // ------------------------------------------------------------------------------------------ pass 2
