@@ -42,6 +42,10 @@
 // y[oy][ox] = sum_{dy,dx in {0,1}} W[2dy+py][2dx+px] X[oy+dy][ox+dx] — the view is only index math in the halo gather
 // (a 'channel chunk' is then 32 channels of one of the four pixel parities), the weights are re-indexed at pack time.
 //
+// UPS == 4 is the 7x7 init conv (CFG:333) with at most 16 input channels: TWO taps share one K = 32 slice (K slots 0..15 =
+// the 16 channels of tap 2t, 16..31 = those of tap 2t + 1: a lane's 8-channel group picks its tap), 25 tap pairs instead of
+// 49 taps whose upper K half would be zero padding.
+//
 // Replaces: the 3x3 convolutions of Block / ResnetBlock CFG:128-170, the Upsample conv CFG:106-107, the Downsample
 // conv CFG:110-111 and the 1x1 convolutions (to_qkv / to_out / res_conv) of CFG:176-245.
 #include <stdlib.h>
@@ -93,7 +97,9 @@ __device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x)
 template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   using Cfg = F16Cfg<KH, KW, S, UPS, TH, TW, WM, WN>;
-  constexpr int IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, NLOAD = Cfg::NLOAD, NTAPS = KH * KW, ROWP = Cfg::ROWP;
+  constexpr bool PK = UPS == 4;  // two taps per K slice (see the header)
+  constexpr int IN_W = Cfg::IN_W, IN_PIX = Cfg::IN_PIX, NLOAD = Cfg::NLOAD, NTAPS = PK ? (KH * KW + 1) / 2 : KH * KW,
+                ROWP = Cfg::ROWP;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   unsigned char* in_tile = reinterpret_cast<unsigned char*>(lds);
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #pragma unroll
   for (int mb = 0; mb < 4; ++mb)
     arow[mb] = UPS == 3 ? (mb + (wm >> 1)) * ROWP + (l15 + (wm & 1)) * PITCH + kg * 16
-                        : ((wm * 4 + mb) * S) * ROWP + (l15 * S) * PITCH + kg * 16;
+                        : ((wm * 4 + mb) * S) * ROWP + (l15 * S) * PITCH + (PK ? (kg & 1) : kg) * 16;
 
   // accumulators: 4 pixel blocks x 4 channel blocks of 16x16.  The MFMA takes the WEIGHT fragment as its first operand, so
   // D = W * X^T: row 4 * (lane >> 4) + r = output channel, column lane & 15 = pixel — a lane holds 4 consecutive channels
@@ -350,6 +356,12 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
                                                     // slot r % 5 (ky = 0 needs rows 0-3, ky = 1 adds row 4, ky = 2 row 5)
     auto read_a = [&](int tap) {
       const unsigned char* at = in_tile + (tap / KW) * ROWP + (tap % KW) * PITCH;
+      if constexpr (PK) {  // `tap` is a pair: K groups 0,1 read tap 2*tap, groups 2,3 tap 2*tap + 1 (the odd one out pairs
+                           // with itself under zero weights)
+        const int t0 = 2 * tap, t1 = 2 * tap + 1 < KH * KW ? 2 * tap + 1 : 2 * tap;
+        const int o0 = (t0 / KW) * ROWP + (t0 % KW) * PITCH, o1 = (t1 / KW) * ROWP + (t1 % KW) * PITCH;
+        at = in_tile + ((kg >> 1) ? o1 : o0);
+      }
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -477,7 +489,7 @@ __global__ __launch_bounds__(64) void f16x3_wscale_kernel(const float* __restric
 //      W2[o][(py, px, c)][dy][dx] = w[o][c][2*dy + py][2*dx + px]   (nch0 = 4 * C0 / 32 chunks)
 __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const float* __restrict__ oscale,
                                          _Float16* __restrict__ wp, int Cout, int C0, int C1, int NTAPS, int nch0,
-                                         int nch1, int64_t total, int s2d) {
+                                         int nch1, int64_t total, int s2d, int pk) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int64_t r = idx;
@@ -513,6 +525,9 @@ __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const floa
     const int cr = (ch - par * nchc) * KC + k;  // real input channel
     const int ky = 2 * (tap >> 1) + (par >> 1), kx = 2 * (tap & 1) + (par & 1);
     if (o < Cout) ws = w[((size_t)o * C0 + cr) * 16 + ky * 4 + kx] / oscale[o];
+  } else if (pk) {  // 7x7, C0 <= 16: K slot k = (tap parity) * 16 + channel of tap pair `tap`
+    const int tt = 2 * tap + (k >> 4), cc = k & 15;
+    if (o < Cout && cc < C0 && tt < 49) ws = w[((size_t)o * C0 + cc) * 49 + tt] / oscale[o];
   } else if (ok && o < Cout) {
     ws = w[((size_t)o * (C0 + C1) + c) * NTAPS + tap] / oscale[o];  // exact: a power of two
   }
@@ -521,8 +536,12 @@ __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const floa
   wp[idx] = plane == 0 ? g1 : g2;
 }
 
+// the 7x7 init conv with few input channels runs two taps per K slice (UPS == 4)
+static bool f16x3_pk(int C0, int C1, int KH) { return KH == 7 && C1 == 0 && C0 <= 16; }
+
 static int64_t f16x3_frag_floats(int Cout, int C0, int C1, int KH, int KW) {
   if (KH == 4) return (int64_t)cdiv(Cout, 64) * (4 * C0 / KC) * 4 * 2 * STEP_U4 * 4;  // as 2x2 over 4*C0 channels
+  if (f16x3_pk(C0, C1, KH)) return (int64_t)cdiv(Cout, 64) * 25 * 2 * STEP_U4 * 4;      // one chunk, 25 tap pairs
   return (int64_t)cdiv(Cout, 64) * (cdiv(C0, KC) + cdiv(C1, KC)) * KH * KW * 2 * STEP_U4 * 4;
 }
 
@@ -538,8 +557,10 @@ int dmh_f16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int K
   hipLaunchKernelGGL(f16x3_wscale_kernel, dim3(cdiv(Cout, 64) * 64), dim3(64), 0, st, w, oscale, Cout,
                      (C0 + C1) * KH * KW);
   const int64_t total = frag * 2;  // fp16 elements
+  const bool pk = f16x3_pk(C0, C1, KH);
   hipLaunchKernelGGL(pack_f16x3_weight_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, st, w, oscale,
-                     reinterpret_cast<_Float16*>(wpack), Cout, C0, C1, s2d ? 4 : KH * KW, nch0, nch1, total, s2d ? 1 : 0);
+                     reinterpret_cast<_Float16*>(wpack), Cout, C0, C1, s2d ? 4 : (pk ? 25 : KH * KW), nch0, nch1, total,
+                     s2d ? 1 : 0, pk ? 1 : 0);
   DMH_CHECK_LAUNCH("dmh_pack_conv_weight(f16x3)");
   return DMH_OK;
 }
@@ -628,9 +649,10 @@ int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
     return wide ? launch_f16x3<2, 2, 1, 2, 8, 16, 2, 2>(d, Hout, Wout, st)
                 : launch_f16x3<2, 2, 1, 2, 16, 16, 4, 1>(d, Hout, Wout, st);
   }
-  if (d->KH == 7)  // init conv (CFG:333): few input channels, so most of each 32-channel K slice is zero padding — still
-                   // ~3x the fp32 MFMA kernel
+  if (d->KH == 7) {  // init conv (CFG:333): few input channels — two taps per 32-channel K slice when they fit
+    if (f16x3_pk(d->C0, d->src1 ? d->C1 : 0, 7)) return launch_f16x3<7, 7, 1, 4, 16, 16, 4, 1>(d, Hout, Wout, st);
     return launch_f16x3<7, 7, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);
+  }
   if (d->KH == 1) {
     static int wide1 = -1;  // development knob
     if (wide1 < 0) {

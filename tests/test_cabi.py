@@ -47,7 +47,9 @@ def test_pure_host_entry_points():
         assert lib.dmh_conv_pack_floats(384, 64, 0, 1, 1) == f16x3(384, 64, 0, 1)
         assert lib.dmh_conv_tiles(128, 128, 3, 1) == 128 and lib.dmh_conv_tiles(128, 128, 1, 1) == 128   # 8x16 stat tiles
     if os.environ.get('DMH_CONV3_VARIANT', '9') == '9':
-        assert lib.dmh_conv_pack_floats(64, 12, 0, 7, 7) == f16x3(64, 12, 0, 49)
+        # 7x7 with <= 16 input channels: two taps per 32-channel K slice -> 25 tap pairs; wider inputs: 49 taps
+        assert lib.dmh_conv_pack_floats(64, 12, 0, 7, 7) == f16x3(64, 12, 0, 25)
+        assert lib.dmh_conv_pack_floats(64, 24, 0, 7, 7) == f16x3(64, 24, 0, 49)
     if os.environ.get('DMH_CONV3_VARIANT', '9') == '9':
         # Downsample 4x4 / stride 2 = 2x2 over the 4*C space-to-depth view when C % 32 == 0, else the fp32 image
         assert lib.dmh_conv_pack_floats(128, 64, 0, 4, 4) == f16x3(128, 256, 0, 4)

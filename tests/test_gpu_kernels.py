@@ -36,6 +36,8 @@ CONV_CASES = [
     ('1x1 concat 40+24->72 5x33', 3, 5, 33, 40, 24, 72, 1, 1, 0),
     ('7x7 12->64 32x32', 2, 32, 32, 12, 0, 64, 7, 1, 0),
     ('7x7 ragged 4->8 21x18', 1, 21, 18, 4, 0, 8, 7, 1, 0),
+    ('7x7 16->32 20x24 (two taps per K slice, all 16 slots used)', 2, 20, 24, 16, 0, 32, 7, 1, 0),
+    ('7x7 20->64 18x18 (one tap per K slice)', 1, 18, 18, 20, 0, 64, 7, 1, 0),
     ('4x4s2 64->128 32x32', 2, 32, 32, 64, 0, 128, 4, 2, 0),
     ('4x4s2 ragged 8->16 22x38', 1, 22, 38, 8, 0, 16, 4, 2, 0),
     ('2x2s2 16->32 24x40', 2, 24, 40, 16, 0, 32, 2, 2, 0),
