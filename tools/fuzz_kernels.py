@@ -35,7 +35,7 @@ for it in range(N):
     co = rnd.choice([4, 8, 20, 64, 72, 128, 256])
     k, stride, ups = {'3x3': (3, 1, 0), '1x1': (1, 1, 0), '7x7': (7, 1, 0), '4x4s2': (4, 2, 0), 'up': (3, 1, 1)}[kind]
     if kind == '7x7':
-        c0, c1 = rnd.choice([4, 12]), 0
+        c0, c1 = rnd.choice([4, 12, 16, 20, 36]), 0      # <= 16: two taps per K slice; wider: one
     if kind == '4x4s2':
         H, W = 2 * rnd.randint(1, 20), 2 * rnd.randint(1, 20)
     pro = kind in ('3x3', '1x1') and c1 == 0 and rnd.random() < 0.5
