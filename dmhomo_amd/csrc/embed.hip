@@ -30,23 +30,34 @@ __device__ __forceinline__ float act_f(float x, int act) {
   return x;
 }
 
-// y[r][o] = act_out(sum_i act_in(x[r][i]) * wt[i][o] + bias[o]); one row per blockIdx.y,
-// 256 output features per blockIdx.x, the (activated) input row staged in LDS.
+// y[r][o] = act_out(sum_i act_in(x[r][i]) * wt[i][o] + bias[o]); one row per blockIdx.y, 64 output features per
+// blockIdx.x, the (activated) input row staged in LDS.  The four waves of a block each take a quarter of the input features
+// (round 2: one thread per output walked all of them — a dependent chain of in_dim loads + FMAs, 14 us per launch for a few
+// MFLOP, a dozen launches at the head of every UNet pass); the quarters are added in a fixed order.
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ wt, const float* __restrict__ bias,
                                                      float* __restrict__ y, int64_t y_stride, int in_dim, int out_dim,
                                                      int act_in, int act_out) {
-  extern __shared__ float xs[];
+  extern __shared__ float xs[];          // in_dim staged inputs, then 4 x 64 partial sums
+  float* red = xs + in_dim;
   const int r = blockIdx.y;
   for (int i = threadIdx.x; i < in_dim; i += 256) xs[i] = act_f(x[r * x_stride + i], act_in);
   __syncthreads();
-  const int o = blockIdx.x * 256 + threadIdx.x;
-  if (o >= out_dim) return;
+  const int ol = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int o = blockIdx.x * 64 + ol;
+  const int oc = o < out_dim ? o : out_dim - 1;      // clamped column: every lane walks its quarter, the store is guarded
+  const int kq = (in_dim + 3) >> 2;
+  const int k0 = ks * kq, k1 = min(k0 + kq, in_dim);
   float acc = 0.f;
 #pragma unroll 8
-  for (int i = 0; i < in_dim; ++i) acc = fmaf(xs[i], wt[(size_t)i * out_dim + o], acc);
-  if (bias) acc += bias[o];
-  y[r * y_stride + o] = act_f(acc, act_out);
+  for (int i = k0; i < k1; ++i) acc = fmaf(xs[i], wt[(size_t)i * out_dim + oc], acc);
+  red[ks * 64 + ol] = acc;
+  __syncthreads();
+  if (ks == 0 && o < out_dim) {
+    float v = (red[ol] + red[64 + ol]) + (red[128 + ol] + red[192 + ol]);
+    if (bias) v += bias[o];
+    y[r * y_stride + o] = act_f(v, act_out);
+  }
 }
 
 extern "C" int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* out, int R, int dim, void* stream) {
@@ -71,7 +82,7 @@ extern "C" int dmh_linear(const float* x, int64_t x_stride, const float* wt, con
                           int64_t y_stride, int R, int in_dim, int out_dim, int act_in, int act_out, void* stream) {
   DMH_REQUIRE(x && wt && y && R > 0 && in_dim > 0 && out_dim > 0, "dmh_linear: bad arguments");
   DMH_REQUIRE(in_dim <= 8192, "dmh_linear: in_dim %d too large", in_dim);
-  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(out_dim, 256), R), dim3(256), in_dim * sizeof(float),
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(out_dim, 64), R), dim3(256), (in_dim + 256) * sizeof(float),
                      (hipStream_t)stream, x, x_stride, wt, bias, y, y_stride, in_dim, out_dim, act_in, act_out);
   DMH_CHECK_LAUNCH("dmh_linear");
   return DMH_OK;
