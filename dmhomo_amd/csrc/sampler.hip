@@ -44,41 +44,57 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
 #pragma unroll
   for (int o = 0; o < COUT; ++o)
     if (sub == o && bias) bo = bias[o];
-  for (int64_t pix = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix < npix; pix += (int64_t)gridDim.x * 16) {
-    float acc[COUT];
-#pragma unroll
-    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+  // U pixels per thread group and iteration: their loads are in flight together (round 2: one pixel per iteration left a
+  // single 16 B load per lane between dependent reduction chains)
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t pix0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix0 < npix; pix0 += stride * U) {
+    float4 v[U];
     if (one) {
-      const float4 v = sub < C4 ? ld4(x + pix * C + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int o = 0; o < COUT; ++o) {
-        acc[o] = fmaf(v.x, wq[o].x, acc[o]);
-        acc[o] = fmaf(v.y, wq[o].y, acc[o]);
-        acc[o] = fmaf(v.z, wq[o].z, acc[o]);
-        acc[o] = fmaf(v.w, wq[o].w, acc[o]);
+      for (int u = 0; u < U; ++u) {
+        const int64_t pix = pix0 + u * stride;
+        v[u] = (sub < C4 && pix < npix) ? ld4(x + pix * C + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    } else {
-      for (int q = sub; q < C4; q += 16) {
-        const float4 v = ld4(x + pix * C + q * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pix = pix0 + u * stride;
+      if (pix >= npix) break;   // (uniform over the 16 lanes of a pixel; the lane sums below stay inside them)
+      float acc[COUT];
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+      if (one) {
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
-          const float4 ww = ld4(w + (size_t)o * C + q * 4);
-          acc[o] = fmaf(v.x, ww.x, acc[o]);
-          acc[o] = fmaf(v.y, ww.y, acc[o]);
-          acc[o] = fmaf(v.z, ww.z, acc[o]);
-          acc[o] = fmaf(v.w, ww.w, acc[o]);
+          acc[o] = fmaf(v[u].x, wq[o].x, acc[o]);
+          acc[o] = fmaf(v[u].y, wq[o].y, acc[o]);
+          acc[o] = fmaf(v[u].z, wq[o].z, acc[o]);
+          acc[o] = fmaf(v[u].w, wq[o].w, acc[o]);
+        }
+      } else {
+        for (int q = sub; q < C4; q += 16) {
+          const float4 vv = ld4(x + pix * C + q * 4);
+#pragma unroll
+          for (int o = 0; o < COUT; ++o) {
+            const float4 ww = ld4(w + (size_t)o * C + q * 4);
+            acc[o] = fmaf(vv.x, ww.x, acc[o]);
+            acc[o] = fmaf(vv.y, ww.y, acc[o]);
+            acc[o] = fmaf(vv.z, ww.z, acc[o]);
+            acc[o] = fmaf(vv.w, ww.w, acc[o]);
+          }
         }
       }
-    }
-    float mine = 0.f;
+      float mine = 0.f;
 #pragma unroll
-    for (int o = 0; o < COUT; ++o) {
-      const float t = row16_sum(acc[o]);   // (every lane of the pixel gets the sum)
-      mine = sub == o ? t : mine;
-    }
-    if (sub < COUT) {
-      const unsigned r = (unsigned)pix / (unsigned)HW, p = (unsigned)pix - r * (unsigned)HW;   // (npix < 2^31: checked at launch)
-      out[((size_t)r * COUT + sub) * HW + p] = mine + bo;
+      for (int o = 0; o < COUT; ++o) {
+        const float t = row16_sum(acc[o]);   // (every lane of the pixel gets the sum)
+        mine = sub == o ? t : mine;
+      }
+      if (sub < COUT) {
+        const unsigned r = (unsigned)pix / (unsigned)HW, p = (unsigned)pix - r * (unsigned)HW;   // (npix < 2^31: checked at launch)
+        out[((size_t)r * COUT + sub) * HW + p] = mine + bo;
+      }
     }
   }
 }
@@ -220,7 +236,7 @@ extern "C" int dmh_final_conv_nchw(const float* x, const float* w, const float* 
   const int64_t npix = (int64_t)R * HW;
   DMH_REQUIRE(npix < ((int64_t)1 << 31), "dmh_final_conv_nchw: %lld pixels (limit 2^31)", (long long)npix);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(grid_for(npix, 16));
+  const dim3 grid(grid_for(npix, 64));   // four pixels per thread group and iteration
 #define DMH_FC(N)                                                                                             \
   case N:                                                                                                     \
     hipLaunchKernelGGL((final_conv_kernel<N>), grid, dim3(256), 0, st, x, w, bias, out, npix, HW, C); \
