@@ -78,7 +78,10 @@ struct F16Cfg {
   static constexpr int IN_H = SUB ? TH + 2 : (TH - 1) * S + KH;
   static constexpr int IN_W = SUB ? TW + 2 : (TW - 1) * S + KW;
   static constexpr int IN_PIX = IN_H * IN_W;
-  static constexpr int NLOAD = (IN_PIX * 8 + 255) / 256;
+  // channel quads staged per pixel: 8 (one 32-channel chunk); UPS == 4 reads only channels 0..15 of a staged pixel (its
+  // K slots 16..31 are another pixel's), so it stages 4 — half the loads, splits and LDS writes, 32 registers less
+  static constexpr int QS = UPS == 4 ? 2 : 3, NQ = 1 << QS;
+  static constexpr int NLOAD = (IN_PIX * NQ + 255) / 256;
   static constexpr int PAD = UPS == 2 ? 0 : ((S == 1) ? (KH / 2) : (KH == 4 ? 1 : 0));  // UPS == 2: cell (oy, ox) is tap (0,0)
   // An A fragment of v_mfma_f32_16x16x32_f16 is 16 pixels of one tile row x 4 K-groups of 16 B.  ds_read_b128 serves
   // lanes in groups of 16 that pair 8 pixels of one K-group with the complementary 8 pixels of the next K-group
@@ -202,13 +205,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 
   // input (halo) tile of one channel chunk: global -> registers, issued one chunk ahead.  Unconditional loads
   // from clamped addresses + a validity mask (see conv.hip) keep them in flight under counted waits.
-  const int c4 = tid & 7;
+  constexpr int QS = Cfg::QS, NQ = Cfg::NQ;
+  const int c4 = tid & (NQ - 1);
   float4 v[NLOAD];
   int poff[NLOAD], wroff[NLOAD];
   unsigned inside = 0;
 #pragma unroll
   for (int i = 0; i < NLOAD; ++i) {
-    const int pix = (tid + i * 256) >> 3;
+    const int pix = (tid + i * 256) >> QS;
     const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
     wroff[i] = (pixc / IN_W) * ROWP + (pixc % IN_W) * PITCH + c4 * 8;  // staging slot in the LDS tile
     const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #endif
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
-      if ((i + 1) * 256 <= IN_PIX * 8 || ((tid + i * 256) >> 3) < IN_PIX) {
+      if ((i + 1) * 256 <= IN_PIX * NQ || ((tid + i * 256) >> QS) < IN_PIX) {
         // h1 = fp16(x * sc), h2 = fp16(x * sc - h1) (exact; see the header: stored unscaled) as eight v_fma_mix — each
         // multiplies, subtracts the fp16 piece and converts in one instruction; hipcc's own sequence for the same values
         // (packed multiply, convert, convert back, packed fma, convert) is twelve
