@@ -30,33 +30,49 @@ __device__ __forceinline__ float act_f(float x, int act) {
   return x;
 }
 
-// y[r][o] = act_out(sum_i act_in(x[r][i]) * wt[i][o] + bias[o]); one row per blockIdx.y, 64 output features per
-// blockIdx.x, the (activated) input row staged in LDS.  The four waves of a block each take a quarter of the input features
+// y[r][o] = act_out(sum_i act_in(x[r][i]) * wt[i][o] + bias[o]); RB rows per blockIdx.y, 64 output features per
+// blockIdx.x, the (activated) input rows staged in LDS.  The four waves of a block each take a quarter of the input features
 // (round 2: one thread per output walked all of them — a dependent chain of in_dim loads + FMAs, 14 us per launch for a few
-// MFLOP, a dozen launches at the head of every UNet pass); the quarters are added in a fixed order.
+// MFLOP, a dozen launches at the head of every UNet pass); the quarters are added in a fixed order.  A weight is loaded once
+// for the block's RB rows (the (scale, shift) projection of all ResnetBlocks, 512 -> 9.5 k features, re-read its 19 MB of
+// weights from L2 for every row: 57 us at 50 rows); every row keeps its own accumulator and summation order, so a row's
+// result does not depend on which rows share its block.
+constexpr int LIN_RB = 4;
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int64_t x_stride,
                                                      const float* __restrict__ wt, const float* __restrict__ bias,
-                                                     float* __restrict__ y, int64_t y_stride, int in_dim, int out_dim,
+                                                     float* __restrict__ y, int64_t y_stride, int R, int in_dim, int out_dim,
                                                      int act_in, int act_out) {
-  extern __shared__ float xs[];          // in_dim staged inputs, then 4 x 64 partial sums
-  float* red = xs + in_dim;
-  const int r = blockIdx.y;
-  for (int i = threadIdx.x; i < in_dim; i += 256) xs[i] = act_f(x[r * x_stride + i], act_in);
+  extern __shared__ float xs[];          // LIN_RB x in_dim staged inputs, then LIN_RB x 4 x 64 partial sums
+  float* red = xs + LIN_RB * in_dim;
+  const int r0 = blockIdx.y * LIN_RB;
+#pragma unroll
+  for (int rr = 0; rr < LIN_RB; ++rr) {
+    const int r = min(r0 + rr, R - 1);   // rows past the end repeat the last one and are not stored
+    for (int i = threadIdx.x; i < in_dim; i += 256) xs[rr * in_dim + i] = act_f(x[r * x_stride + i], act_in);
+  }
   __syncthreads();
   const int ol = threadIdx.x & 63, ks = threadIdx.x >> 6;
   const int o = blockIdx.x * 64 + ol;
   const int oc = o < out_dim ? o : out_dim - 1;      // clamped column: every lane walks its quarter, the store is guarded
   const int kq = (in_dim + 3) >> 2;
   const int k0 = ks * kq, k1 = min(k0 + kq, in_dim);
-  float acc = 0.f;
+  float acc[LIN_RB];
+#pragma unroll
+  for (int rr = 0; rr < LIN_RB; ++rr) acc[rr] = 0.f;
 #pragma unroll 8
-  for (int i = k0; i < k1; ++i) acc = fmaf(xs[i], wt[(size_t)i * out_dim + oc], acc);
-  red[ks * 64 + ol] = acc;
+  for (int i = k0; i < k1; ++i) {
+    const float w = wt[(size_t)i * out_dim + oc];
+#pragma unroll
+    for (int rr = 0; rr < LIN_RB; ++rr) acc[rr] = fmaf(xs[rr * in_dim + i], w, acc[rr]);
+  }
+#pragma unroll
+  for (int rr = 0; rr < LIN_RB; ++rr) red[(rr * 4 + ks) * 64 + ol] = acc[rr];
   __syncthreads();
-  if (ks == 0 && o < out_dim) {
-    float v = (red[ol] + red[64 + ol]) + (red[128 + ol] + red[192 + ol]);
+  if (o < out_dim && r0 + ks < R) {      // wave ks finishes row r0 + ks
+    const float* q = red + (ks * 4) * 64 + ol;
+    float v = (q[0] + q[64]) + (q[128] + q[192]);
     if (bias) v += bias[o];
-    y[r * y_stride + o] = act_f(v, act_out);
+    y[(r0 + ks) * y_stride + o] = act_f(v, act_out);
   }
 }
 
@@ -81,9 +97,10 @@ extern "C" int dmh_class_embed(const int64_t* classes, const uint8_t* keep, cons
 extern "C" int dmh_linear(const float* x, int64_t x_stride, const float* wt, const float* bias, float* y,
                           int64_t y_stride, int R, int in_dim, int out_dim, int act_in, int act_out, void* stream) {
   DMH_REQUIRE(x && wt && y && R > 0 && in_dim > 0 && out_dim > 0, "dmh_linear: bad arguments");
-  DMH_REQUIRE(in_dim <= 8192, "dmh_linear: in_dim %d too large", in_dim);
-  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(out_dim, 64), R), dim3(256), (in_dim + 256) * sizeof(float),
-                     (hipStream_t)stream, x, x_stride, wt, bias, y, y_stride, in_dim, out_dim, act_in, act_out);
+  DMH_REQUIRE(in_dim <= 3584, "dmh_linear: in_dim %d too large (the block stages 4 input rows in 60 KB of LDS)", in_dim);
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(out_dim, 64), cdiv(R, LIN_RB)), dim3(256),
+                     LIN_RB * (in_dim + 256) * sizeof(float), (hipStream_t)stream, x, x_stride, wt, bias, y, y_stride, R,
+                     in_dim, out_dim, act_in, act_out);
   DMH_CHECK_LAUNCH("dmh_linear");
   return DMH_OK;
 }
