@@ -430,6 +430,23 @@ def test_embeddings(ops):
     close('mlp silu-in', y.cpu(), F.linear(F.silu(x), w), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize('R,i,o', [(7, 512, 200), (50, 96, 1000), (5, 1, 70), (9, 333, 64)])
+def test_linear_rows_independent_and_ragged(ops, R, i, o):
+    """dmh_linear shares each weight load between the rows of a block: a row's result must not depend on the rows beside it
+    (ragged row counts and feature counts that are no multiple of the block's 4 rows / 64 columns / 4 input quarters)"""
+    x = rand((R, i), 71).to(dev())
+    wt = rand((i, o), 72, i ** -0.5).to(dev())
+    b = rand((o,), 73).to(dev())
+    y = ops.linear(x, wt, b, act_in='silu', act_out='gelu')
+    ref = F.gelu(F.linear(F.silu(x.double().cpu()), wt.double().cpu().t(), b.double().cpu()))
+    close(f'linear {R}x{i}->{o}', y.cpu().double(), ref, rtol=1e-5, atol=2e-6)
+    for r in (0, R // 2, R - 1):
+        alone = ops.linear(x[r:r + 1].contiguous(), wt, b, act_in='silu', act_out='gelu')
+        assert torch.equal(alone[0], y[r]), r
+    tail = ops.linear(x[R - 3:].contiguous(), wt, b, act_in='silu', act_out='gelu')
+    assert torch.equal(tail, y[R - 3:])
+
+
 # ---------------------------------------------------------------------------- sampler glue
 def test_assemble_and_final_conv(ops):
     x, rf, m = rand((2, 6, 9, 11), 24), rand((2, 3, 9, 11), 25), (rand((2, 1, 9, 11), 26) > 0).float()
