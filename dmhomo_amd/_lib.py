@@ -23,7 +23,8 @@ c_float = C.c_float
 class DmhConv(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('src0', 'src1', 'wpack', 'bias', 'in_coef', 'res', 'res_coef', 'out',
                                           'stats')] + \
-               [(n, C.c_int32) for n in ('B', 'Hin', 'Win', 'C0', 'C1', 'Cout', 'KH', 'KW', 'stride', 'upsample2')]
+               [(n, C.c_int32) for n in ('B', 'Hin', 'Win', 'C0', 'C1', 'Cout', 'KH', 'KW', 'stride', 'upsample2')] + \
+               [('in_bound', C.c_void_p), ('in_bound_n', C.c_int32)]
 
 
 class DmhStep(C.Structure):
@@ -45,6 +46,8 @@ SIGNATURES = {
     'dmh_conv2d': (c_int, [C.POINTER(DmhConv), C.c_void_p]),
     'dmh_gn_finalize': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int,
                                 c_float, C.c_void_p]),
+    'dmh_gn_finalize_bound': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_int, c_int, c_int,
+                                      c_int, c_float, C.c_void_p]),
     'dmh_gn_silu_residual': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
     'dmh_gn_silu_residual_stats': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, C.c_void_p]),
     'dmh_chan_layernorm': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),

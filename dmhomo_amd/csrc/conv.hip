@@ -406,6 +406,8 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
   DMH_REQUIRE(!(d->in_coef && d->src1), "dmh_conv2d: the GroupNorm prologue applies to a single source");
   DMH_REQUIRE(!(d->res_coef && !d->res), "dmh_conv2d: res_coef without res");
   DMH_REQUIRE(d->Cout % 4 == 0, "dmh_conv2d: Cout must be a multiple of 4 (got %d)", d->Cout);
+  DMH_REQUIRE(!d->in_bound || (d->in_coef && d->in_bound_n > 0 && d->in_bound_n <= 64),
+              "dmh_conv2d: in_bound needs in_coef and 1..64 bounds per sample (got %d)", d->in_bound_n);
   hipStream_t st = (hipStream_t)stream;
   const int Hout = conv_out_dim(d->Hin, d->KH, d->stride, d->upsample2);
   const int Wout = conv_out_dim(d->Win, d->KW, d->stride, d->upsample2);

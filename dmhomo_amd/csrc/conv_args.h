@@ -15,6 +15,8 @@ struct ConvArgs {
   float* out;
   float* stats;
   const float* oscale;  // per-output-channel power-of-two factor undoing the weight scaling (conv_f16x3.hip), or null
+  const float* in_bound;  // null or [B][in_bound_n]: upper bounds of the prologue's |a*x + b| per sample (DmhConv.in_bound)
+  int in_bound_n;
   int B, Hin, Win, C0, C1, Cout, Hout, Wout;
   int nch0, nch1, tilesX, tilesY;
   int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
@@ -34,6 +36,8 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
   a.out = d->out;
   a.stats = d->stats;
   a.oscale = nullptr;
+  a.in_bound = d->in_coef ? d->in_bound : nullptr;
+  a.in_bound_n = d->in_bound_n;
   a.B = d->B;
   a.Hin = d->Hin;
   a.Win = d->Win;

@@ -264,6 +264,19 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   __syncthreads();                              // block-maximum slots are zeroed
 
   int e_run = 16;  // biased exponent of the running block maximum (clamped to [16, 254]); uniform
+  // DmhConv.in_bound: the producer's GroupNorm statistics bound |a*x + b| >= |SiLU(a*x + b)| for every element of the sample,
+  // so the block scale is known before the tile arrives: no maximum over the staged values, no LDS atomic, no wait for it
+  // (an over-estimated scale costs range, not precision: see the header), one scale for all chunks, never a rescale
+  bool stat = p.in_bound != nullptr;
+  int e_fix = 16;
+  if (stat) {
+    float m = 0.f;
+    for (int i = 0; i < p.in_bound_n; ++i) m = fmaxf(m, p.in_bound[b * p.in_bound_n + i]);
+    const unsigned mb = __builtin_amdgcn_readfirstlane(__float_as_uint(m));
+    stat = mb < 0x7f000000u;   // +inf (or NaN): the producer declined to bound this sample -> search the tiles as usual
+    // + 1: a factor of two for the rounding of the bound and of the prologue's own fma
+    e_fix = min(max((int)(mb >> 23) + 1, 16), 254);
+  }
   for (int ch = 0; ch < nchunks; ++ch) {
     const bool s1c = ch >= p.nch0;
     const bool pro = (p.in_coef != nullptr) && !s1c;
@@ -295,21 +308,26 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     // block maximum over everything the lanes hold, padding lanes included (their values are real ones from clamped
     // addresses: the scale only has to bound the tile, and an over-estimate costs nothing — see the header); the padding
     // itself becomes zero in the split below, which multiplies it by 0 instead of the block scale
-    float mxf = 0.f;
+    if (!stat) {
+      float mxf = 0.f;
 #pragma unroll
-    for (int i = 0; i < NLOAD; ++i)
-      mxf = fmaxf(fmaxf(mxf, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
-    unsigned mx = __float_as_uint(mxf);
-    mx = wave_max_u32(mx);
-    if (lane == 0) atomicMax(&mxslot[ch & 1], mx);
+      for (int i = 0; i < NLOAD; ++i)
+        mxf = fmaxf(fmaxf(mxf, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+      unsigned mx = __float_as_uint(mxf);
+      mx = wave_max_u32(mx);
+      if (lane == 0) atomicMax(&mxslot[ch & 1], mx);
+    }
     STAMP(0)  // wait for the halo loads + prologue + block maximum
     __syncthreads();  // block maximum complete; every wave is done reading the previous chunk's tile
     STAMP(1)  // barrier 1
-    const unsigned bmx = mxslot[ch & 1];
-    if (tid == 0) mxslot[(ch + 1) & 1] = 0u;
     // ---- block scale: running maximum over the chunks, so the scale only ever shrinks (no overflow on rescale)
     const int e_old = e_run;
-    const int e_ch = min(max((int)(__builtin_amdgcn_readfirstlane(bmx) >> 23), 16), 254);
+    int e_ch = e_fix;
+    if (!stat) {
+      const unsigned bmx = mxslot[ch & 1];
+      if (tid == 0) mxslot[(ch + 1) & 1] = 0u;
+      e_ch = min(max((int)(__builtin_amdgcn_readfirstlane(bmx) >> 23), 16), 254);
+    }
     e_run = max(e_run, e_ch);
     const float sc = __uint_as_float((unsigned)(268 - e_run) << 23);  // largest |x| * sc in [2^14, 2^15)
     if (e_run != e_old && ch > 0) {

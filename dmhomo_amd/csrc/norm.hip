@@ -11,8 +11,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ ss,
                                                           int64_t ss_stride, float* __restrict__ coef, int C, int groups,
-                                                          int hw, float eps, float* __restrict__ mr) {
+                                                          int hw, float eps, float* __restrict__ mr,
+                                                          float* __restrict__ bound) {
   __shared__ double red[2][4];
+  __shared__ float bred[4];
   const int b = blockIdx.x / groups, g = blockIdx.x % groups;
   const int cg = C / groups;
   const int lane = threadIdx.x;
@@ -45,6 +47,15 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     mr[(size_t)blockIdx.x * 2 + 0] = meanf;
     mr[(size_t)blockIdx.x * 2 + 1] = rstd;
   }
+  // bound (optional): an upper bound of |a*x + b| over every element x of this (sample, group), for a consumer that needs
+  // the magnitude of its prologue's input without looking at the data (conv_f16x3.hip's block scale): |x - mean| <=
+  // sqrt(sum (x - mean)^2) <= sqrt(sum x^2) — the accumulated s2, a sum of positive terms, no cancellation — so
+  // |a*x + b| <= |a| * sqrt(s2) + |b + mean*a|.  (sqrt(n) standard deviations when the mean is small: far above the largest
+  // element, which costs a block-scaled fp16 split range, not precision.)
+  // When |mean| is more than 64 standard deviations the bound is that much looser than the data (and the variance itself is
+  // what cancellation left of it): +inf then tells the consumer to look at the data instead.
+  const float spread = (s2 > 4096.0 * n * (var + (double)eps)) ? INFINITY : (float)sqrt(s2 > 0.0 ? s2 : 0.0);
+  float bmax = 0.f;
   for (int cc = lane; cc < cg; cc += 256) {
     const int c = g * cg + cc;
     float a = rstd * gamma[c];
@@ -57,6 +68,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
     coef[(size_t)(b * 2 + 0) * C + c] = a;
     coef[(size_t)(b * 2 + 1) * C + c] = bb;
+    bmax = fmaxf(bmax, fmaf(fabsf(a), spread, fabsf(fmaf(meanf, a, bb))));
+  }
+  if (bound) {
+    for (int off = 32; off; off >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, off));
+    if ((lane & 63) == 0) bred[lane >> 6] = bmax;
+    __syncthreads();
+    if (lane == 0) bound[blockIdx.x] = fmaxf(fmaxf(bred[0], bred[1]), fmaxf(bred[2], bred[3]));
   }
 }
 
@@ -170,8 +188,21 @@ extern "C" int dmh_gn_finalize(const float* stats, int tiles, const float* gamma
   DMH_REQUIRE(stats && gamma && beta && coef, "dmh_gn_finalize: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize: bad shape");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
-                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr);
+                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr, (float*)nullptr);
   DMH_CHECK_LAUNCH("dmh_gn_finalize");
+  return DMH_OK;
+}
+
+// same, also writing bound [B][groups]: an upper bound of |a*x + b| over each (sample, group) of the tensor the statistics
+// were taken from — DmhConv.in_bound of the conv that applies this affine in its prologue
+extern "C" int dmh_gn_finalize_bound(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
+                                     int64_t ss_stride, float* coef, float* bound, int B, int C, int groups, int hw,
+                                     float eps, void* stream) {
+  DMH_REQUIRE(stats && gamma && beta && coef && bound, "dmh_gn_finalize_bound: null pointer");
+  DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize_bound: bad shape");
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
+                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr, bound);
+  DMH_CHECK_LAUNCH("dmh_gn_finalize_bound");
   return DMH_OK;
 }
 
@@ -182,7 +213,7 @@ extern "C" int dmh_gn_finalize_train(const float* stats, int tiles, const float*
   DMH_REQUIRE(stats && gamma && beta && coef && mr, "dmh_gn_finalize_train: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize_train: bad shape");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
-                     ss, ss_stride, coef, C, groups, hw, eps, mr);
+                     ss, ss_stride, coef, C, groups, hw, eps, mr, (float*)nullptr);
   DMH_CHECK_LAUNCH("dmh_gn_finalize_train");
   return DMH_OK;
 }

@@ -190,8 +190,11 @@ class UnetEngine:
         hw = H * W
         y1, st1 = ops.conv2d(r.conv1, x0, x1, want_stats=True)
         ss = ss_all[:, r.ss_off:r.ss_off + 2 * r.cout]
-        coef1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss)
-        y2, st2 = ops.conv2d(r.conv2, y1, in_coef=coef1, want_stats=True)
+        if ops.STATIC_BOUND:
+            coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss, want_bound=True)
+        else:
+            coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss), None
+        y2, st2 = ops.conv2d(r.conv2, y1, in_coef=coef1, want_stats=True, in_bound=bound1)
         coef2 = ops.gn_finalize(st2, r.g2, r.b2, hw, self.groups)
         if r.res is not None:
             x = ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2)

@@ -66,8 +66,9 @@ def conv_out_hw(pc, h, w):
 CONV_LOG = None
 
 
-def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False):
-    """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats)."""
+def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False, in_bound=None):
+    """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats).
+    in_bound (B, k), with in_coef: upper bounds of the prologue's |a*x+b| per sample (gn_finalize(want_bound=True))."""
     B, H, W, c0 = src0.shape
     assert c0 == pc.c0 and (pc.c1 == 0) == (src1 is None), (src0.shape, pc.c0, pc.c1)
     if src1 is not None:
@@ -81,7 +82,8 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
     if res is not None:
         assert res.shape == out.shape, (res.shape, out.shape)
     d = _lib.DmhConv(ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
-                     ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2)
+                     ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2,
+                     ptr(in_bound), 0 if in_bound is None else in_bound.shape[1])
     if CONV_LOG is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -94,14 +96,25 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
 
 
 # ------------------------------------------------------------------ normalisation glue
-def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5):
-    """N2: stats (B,tiles,C,2) -> coef (B,2,C).  ss: (B, >=2C) view whose row b starts with (scale[C], shift[C])."""
+# development knob (A/B runs): DMH_CONV_STATIC_BOUND=0 lets the fp16-piece convs search their staged tiles for the block
+# maximum even where the producer's GroupNorm statistics bound it
+STATIC_BOUND = os.environ.get('DMH_CONV_STATIC_BOUND', '1') != '0'
+
+
+def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5, want_bound=False):
+    """N2: stats (B,tiles,C,2) -> coef (B,2,C).  ss: (B, >=2C) view whose row b starts with (scale[C], shift[C]).
+    want_bound: -> (coef, bound) with bound (B, groups) >= |a*x + b| over each (sample, group): ``conv2d(in_bound=)``."""
     B, tiles, Cc, _ = stats.shape
     coef = _empty((B, 2, Cc), stats)
     ss_ptr, ss_stride = None, 0
     if ss is not None:
         assert ss.stride(1) == 1 and ss.shape[0] == B and ss.shape[1] == 2 * Cc
         ss_ptr, ss_stride = C.c_void_p(ss.data_ptr()), ss.stride(0)
+    if want_bound:
+        bound = _empty((B, groups), stats)
+        call('dmh_gn_finalize_bound', ptr(stats), tiles, ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(coef), ptr(bound),
+             B, Cc, groups, hw, float(eps))
+        return coef, bound
     call('dmh_gn_finalize', ptr(stats), tiles, ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(coef), B, Cc, groups,
          hw, float(eps))
     return coef

@@ -90,6 +90,11 @@ typedef struct DmhConv {
   int32_t stride;     /* 1 or 2 */
   int32_t upsample2;  /* 1: nearest x2 of the input fused into the 3x3 gather (Upsample, CFG:106-107);
                          2: the same conv with a wpack from dmh_pack_conv_weight_up2 (four 2x2 sub-pixel convs) */
+  /* optional, with in_coef: in_bound[b * in_bound_n + i], i < in_bound_n — upper bounds of |a*x + b| over the elements
+   * of sample b (dmh_gn_finalize_bound: one per GroupNorm group).  The fp16-piece kernels then take their block scale
+   * from max_i in_bound instead of searching the staged tile for its maximum; the result is the same convolution. */
+  const float* in_bound;
+  int32_t in_bound_n;
 } DmhConv;
 
 /* tiles per sample that dmh_conv2d will use for this geometry (size of the stats buffer) */
@@ -106,6 +111,12 @@ int dmh_conv2d(const DmhConv* d, void* stream);
  * (scale[C], shift[C]) (ResnetBlock mlp output chunk(2), CFG:233-235). Reduction in f64, fixed order. */
 int dmh_gn_finalize(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
                     int64_t ss_stride, float* coef, int B, int C, int groups, int hw, float eps, void* stream);
+
+/* dmh_gn_finalize + bound[B][groups]: max over the group's channels of |a| * sqrt(sum x^2) + |b + mean*a| >= |a*x + b|
+ * for every element x of the (sample, group) the statistics describe (DmhConv.in_bound) */
+int dmh_gn_finalize_bound(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
+                          int64_t ss_stride, float* coef, float* bound, int B, int C, int groups, int hw, float eps,
+                          void* stream);
 
 /* out = SiLU(a*y + b) + res   (identity res_conv branch of ResnetBlock, CFG:225,241) */
 int dmh_gn_silu_residual(const float* y, const float* coef, const float* res, float* out, int B, int HW, int C,

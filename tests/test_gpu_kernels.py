@@ -246,6 +246,47 @@ def test_gn_silu_residual_pixel_stats_rejects_other_widths(ops):
         ops.gn_silu_residual(y, coef, None, pixel_stats=True)
 
 
+@pytest.mark.parametrize('kind', ['plain', 'offset mean', 'one outlier', 'tiny', 'huge', 'constant'])
+@pytest.mark.parametrize('C,H', [(64, 24), (128, 12)])
+def test_conv_prologue_static_bound(ops, kind, C, H):
+    """Block 2 of a ResnetBlock (CFG:204-213) with its block scale taken from the producer's GroupNorm statistics
+    (dmh_gn_finalize_bound -> DmhConv.in_bound) instead of a search of the staged tiles: the bound holds for every element
+    whatever the data look like, and the convolution is the same one to fp32-accumulation accuracy"""
+    B, groups = 2, 8
+    y = rand((B, H, H, C), 81)
+    if kind == 'offset mean':
+        y = y * 0.01 + 300.0                      # |mean| >> sigma: the variance estimate cancels, the bound must not
+    elif kind == 'one outlier':
+        y[0, 3, 5, 7] = 4.0e4
+        y[1, H - 1, H - 1, C - 1] = -9.0e3
+    elif kind == 'tiny':
+        y = y * 1e-18
+    elif kind == 'huge':
+        y = y * 1e12 + 3e11
+    elif kind == 'constant':
+        y = torch.full_like(y, 2.5)
+    y = y.to(dev())
+    # per-tile GroupNorm partials of y, as a producing conv would write them: one 'tile' holding the whole sample
+    st = torch.stack([y.sum((1, 2)), (y * y).sum((1, 2))], -1).reshape(B, 1, C, 2).contiguous()
+    g, b = (1 + 0.3 * rand((C,), 82)).to(dev()), (0.2 * rand((C,), 83)).to(dev())
+    ss = torch.cat([0.3 * rand((B, C), 84), 0.3 * rand((B, C), 85)], 1).contiguous().to(dev())
+    coef, bound = ops.gn_finalize(st, g, b, H * H, groups, ss, want_bound=True)
+    assert torch.equal(coef, ops.gn_finalize(st, g, b, H * H, groups, ss))
+    z = torch.nn.functional.silu(coef[:, 0].reshape(B, 1, 1, C).double() * y.double() + coef[:, 1].reshape(B, 1, 1, C).double())
+    zmax = z.abs().reshape(B, -1, groups, C // groups).amax((1, 3))
+    assert bool((bound.double() >= zmax).all()), (bound, zmax)       # (+inf: 'look at the data', |mean| > 64 sigma)
+    assert bool(torch.isinf(bound).all()) == (kind in ('offset mean', 'constant')), bound
+    w = rand((C, C, 3, 3), 86, (9 * C) ** -0.5)
+    pc = ops.PackedConv(w.to(dev()), rand((C,), 87, 0.1).to(dev()), C)
+    dyn = ops.conv2d(pc, y, in_coef=coef)
+    sta = ops.conv2d(pc, y, in_coef=coef, in_bound=bound)
+    ref = F.conv2d(z.permute(0, 3, 1, 2).cpu(), w.double(), pc.bias.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    scale = float(ref.abs().max().clamp_min(1e-30))
+    assert bool(torch.isfinite(sta).all())
+    e_dyn, e_sta = float((dyn.cpu().double() - ref).abs().max()) / scale, float((sta.cpu().double() - ref).abs().max()) / scale
+    assert e_sta < 3e-6 and e_sta < 2 * e_dyn + 5e-7, (kind, e_dyn, e_sta)
+
+
 def test_gn_constant_input_is_beta(ops):
     """known answer: GroupNorm of a constant tensor = beta (variance 0 -> (x-mean) = 0)"""
     B, C, H, W = 1, 16, 8, 8

@@ -34,6 +34,8 @@ def main():
     ap.add_argument('--reps', type=int, default=20)
     ap.add_argument('--only', type=str, default='')
     ap.add_argument('--batch', type=int, default=0, help='override the row count B')
+    ap.add_argument('--bound', action='store_true', help='prologue shapes: pass DmhConv.in_bound (the block scale from a '
+                    'producer-side bound instead of a search of the staged tiles)')
     ap.add_argument('--zeros', action='store_true', help='all-zero activations and weights: the same instruction stream at '
                     'minimal switching power; a large speed-up against random data means the kernel sits on the power limit')
     args = ap.parse_args()
@@ -60,13 +62,16 @@ def main():
                 rcoef = torch.stack([1 + 0.1 * torch.randn(B, Cout, device=dev), 0.1 * torch.randn(B, Cout, device=dev)], 1).contiguous()
         if pro == 1:
             coef = torch.stack([1 + 0.1 * torch.randn(B, C0, device=dev), 0.1 * torch.randn(B, C0, device=dev)], 1).contiguous()
+        bound = torch.full((B, 8), 32.0, device=dev) if (args.bound and coef is not None) else None   # >= |a*x+b| here
         for _ in range(3):
-            out = ops.conv2d(pc, s0, s1, in_coef=coef, res=res, res_coef=rcoef, want_stats=(k == 3 and pc.upsample2 != 2))
+            out = ops.conv2d(pc, s0, s1, in_coef=coef, res=res, res_coef=rcoef, want_stats=(k == 3 and pc.upsample2 != 2),
+                             in_bound=bound)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(args.reps):
-            out = ops.conv2d(pc, s0, s1, in_coef=coef, res=res, res_coef=rcoef, want_stats=(k == 3 and pc.upsample2 != 2))
+            out = ops.conv2d(pc, s0, s1, in_coef=coef, res=res, res_coef=rcoef, want_stats=(k == 3 and pc.upsample2 != 2),
+                             in_bound=bound)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / args.reps * 1e3
