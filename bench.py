@@ -84,7 +84,7 @@ def launch_ranks(n, argv):
         sys.exit(rc if rc != 0 else 1)
 
 
-def cpu_baseline(dim, image_size, seconds=12.0):
+def cpu_baseline(dim, image_size, seconds=12.0, slice_bs=0):
     """oracle (kind 'port') on the host cores: bs=2, s_step=4 passes of the same network, reported as
     images/s at s_step=32 (cost per denoise step is constant, so x 4/32)."""
     import torch
@@ -118,11 +118,25 @@ def cpu_baseline(dim, image_size, seconds=12.0):
         if el >= seconds or n >= 6:
             break
     per_pass = el / n
-    return {'value': B * (S / 32.0) / per_pass, 'unit': 'images/s (s_step=32 equivalent)', 'cores': cores,
-            'kind': 'port',
-            'sample': f'oracle cfg_sample bs={B} s_step={S} {image_size}x{image_size} dim={dim}, {n} passes, '
-                      f'{per_pass:.2f} s/pass = {per_pass / S * 1000:.0f} ms per denoise step (bs={B}); '
-                      f'images/s scaled by 4/32 to s_step=32'}
+    res = {'value': B * (S / 32.0) / per_pass, 'unit': 'images/s (s_step=32 equivalent)', 'cores': cores,
+           'kind': 'port',
+           'sample': f'oracle cfg_sample bs={B} s_step={S} {image_size}x{image_size} dim={dim}, {n} passes, '
+                     f'{per_pass:.2f} s/pass = {per_pass / S * 1000:.0f} ms per denoise step (bs={B}); '
+                     f'images/s scaled by 4/32 to s_step=32'}
+    if slice_bs:
+        # SURVEY 8d's second CPU row: a slice of the headline configuration itself (bs = 25, s_step = 2), extrapolated x16
+        Bs, Ss = slice_bs, 2
+        rgb2 = torch.rand((Bs, 3, image_size, image_size), generator=g)
+        mask2 = (torch.rand((Bs, 1, image_size, image_size), generator=g) > 0.5).float()
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            OD.cfg_sample(sd, buf, torch.zeros(Bs, dtype=torch.long), rgb2, torch.zeros((Bs, 2, image_size, image_size)),
+                          mask2, image_size=image_size, channels=6, sampling_timesteps=Ss, objective='pred_x0')
+        el2 = time.perf_counter() - t1
+        res['slice'] = {'value': Bs * (Ss / 32.0) / el2, 'unit': 'images/s (s_step=32 equivalent)', 'cores': cores,
+                        'sample': f'oracle cfg_sample bs={Bs} s_step={Ss} (one pass, {el2:.1f} s), EXTRAPOLATED x16 to '
+                                  f's_step=32: the cost per denoise step is constant'}
+    return res
 
 
 def plumbing_only(args):
@@ -223,9 +237,8 @@ def main():
     diffusion = cfg.GaussianDiffusion(model, image_size=args.image_size, timesteps=1000,
                                       sampling_timesteps=args.s_step, loss_type='l1', objective='pred_x0').to(device)
     D.broadcast_module_(diffusion, src=0)
-    # (one graph holds every kernel of the whole loop: ~21 k nodes at s_step = 32; the 250-step stress configuration would
-    # be a 165 k-node graph and stays on eager launches)
-    use_graph = not args.no_graph and args.s_step <= 64
+    # (ONE denoise step is captured and replayed s_step times: any depth, the 250-step stress configuration included)
+    use_graph = not args.no_graph
     diffusion.hip_graph = use_graph
     torch.manual_seed(99 + rank)                         # device Philox stream for the noise
 
@@ -303,8 +316,10 @@ def main():
             'config': {'workload': f'DGM CFG-Unet dim={args.dim} {args.image_size}x{args.image_size} '
                                    f'bs={args.bs}/GPU s_step={args.s_step} cond_scale=3 ' + (
                                        '(BASELINE configs[1])' if (args.dim, args.image_size, args.bs, args.s_step) ==
-                                       (64, 128, 25, 32) else '(BASELINE configs[4], stress)' if
+                                       (64, 128, 25, 32) else '(BASELINE configs[4], stress; NOT the headline)' if
                                        (args.dim, args.image_size, args.bs, args.s_step) == (128, 256, 8, 250) else
+                                       '(README / DGM/dgm_sample.py:28-38 geometry image_size=256; NOT the headline)' if
+                                       (args.dim, args.image_size, args.bs, args.s_step) == (64, 256, 25, 32) else
                                        '(non-BASELINE configuration)'),
                        'global_batch': args.bs * world, 'sharding': f'samples x{world}, no data-path collective',
                        'cfg_mode': args.cfg_mode, 'hip_graph': use_graph,
@@ -322,8 +337,10 @@ def main():
                         'samples (tests/test_gpu_unet.py::test_fullsize_rows_independent_and_cfg_modes_agree)'}}
         if log:
             res['roofline'] = roofline(log, args)
-        if world == 1 and not args.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(args.dim, args.image_size)
+        if not args.no_cpu_baseline:         # rank 0's host cores, whatever N is (the other ranks wait at the barrier)
+            big = args.dim * args.image_size > 64 * 128
+            res['cpu_baseline'] = cpu_baseline(args.dim, args.image_size, seconds=4.0 if big else 12.0,
+                                               slice_bs=0 if big else args.bs)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
@@ -335,7 +352,8 @@ def roofline(log, args):
     fl3 = ms3 = n3 = 0.0            # stride-1 3x3 launches (the dominant kernel): 3 executed fp16 FLOPs per algorithmic one
     flc = msc = nc = 0.0            # of those, the canonical 64->64 @ image_size^2 with the GN+SiLU prologue
     flu = msu = 0.0                 # sub-pixel Upsample convs (16 of every 36 taps executed): reported, not in `frac`
-    for e0, e1, k, stride, B, ho, wo, cin, cout, ups in log:
+    flq = msq = nq = 0.0            # the same shape WITHOUT the prologue (block 1 of a ResnetBlock): reported beside it
+    for e0, e1, k, stride, B, ho, wo, cin, cout, ups, pro in log:
         if k != 3:
             continue
         ms = e0.elapsed_time(e1)
@@ -345,14 +363,20 @@ def roofline(log, args):
             continue
         fl3, ms3, n3 = fl3 + fl, ms3 + ms, n3 + 1
         if (cin, cout, ho) == (64, 64, args.image_size):
-            flc, msc, nc = flc + fl, msc + ms, nc + 1
+            if pro:
+                flc, msc, nc = flc + fl, msc + ms, nc + 1
+            else:
+                flq, msq, nq = flq + fl, msq + ms, nq + 1
+    if not ms3:                      # (a configuration without a stride-1 3x3 launch in the log)
+        return {'bound': 'mfma', 'achieved': None, 'peak': PEAK_FP16_MFMA_TFLOPS / F16X3_TERMS, 'unit': 'TFLOP/s',
+                'frac': None, 'traffic': None, 'note': 'no stride-1 3x3 conv launch was logged'}
     ach = fl3 / (ms3 * 1e-3) / 1e12
     peak = PEAK_FP16_MFMA_TFLOPS / F16X3_TERMS
     rows = 2 * args.bs
     canon_bytes = 4.0 * rows * args.image_size ** 2 * (64 + 64) + 4 * (9 * 64 * 64 + 3 * 64) + 8 * rows * 64
     canon_us = msc / max(nc, 1) * 1e3
     traffic, traffic_src = None, None
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         tpath = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(tpath):       # FETCH_SIZE / WRITE_SIZE passes of rocprofv3 (tools/profile_round.sh)
             with open(tpath) as f:
@@ -373,7 +397,10 @@ def roofline(log, args):
         'measured_in': 'one extra untimed step, cfg_mode=batched, HIP events on the launch stream',
         'launches': int(n3), 'avg_launch_us': ms3 / max(n3, 1) * 1e3,
         'algorithmic_flop_per_launch': fl3 / max(n3, 1),
+        'same_shape_without_prologue': {'launches': int(nq), 'avg_launch_us': (msq / nq * 1e3) if nq else None},
         'canonical_64to64_128sq': {'launches': int(nc), 'avg_launch_us': canon_us,
+                                   'what': 'conv3x3 64->64 at image_size^2 WITH the fused GroupNorm+SiLU prologue (block 2 of '
+                                           'a ResnetBlock) and the GroupNorm partials in the epilogue',
                                    'TFLOP/s': (flc / (msc * 1e-3) / 1e12) if msc else None,
                                    'algorithmic_bytes_per_launch': canon_bytes,
                                    'GB/s_algorithmic': (canon_bytes / (canon_us * 1e-6) / 1e9) if msc else None},

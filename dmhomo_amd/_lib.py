@@ -117,6 +117,9 @@ SIGNATURES = {
     'dmh_final_conv_nchw': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
     'dmh_sampler_step': (c_int, [C.POINTER(DmhStep), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64,
                                  C.c_void_p]),
+    'dmh_sampler_step_dev': (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_void_p]),
+    'dmh_sampler_seek': (c_int, [C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int,
+                                 C.c_void_p]),
     'dmh_affine': (c_int, [c_f32p, c_f32p, c_float, c_float, c_i64, C.c_void_p]),
     'dmh_affine_tail': (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_float, c_float, C.c_void_p]),
     'dmh_q_sample': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_i64, C.c_void_p]),

@@ -306,11 +306,14 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                         '(CFG:656 vs CFG:719-720); use sampling_timesteps < timesteps (DDIM), or the unconditional '
                         'denoising_diffusion_pytorch.GaussianDiffusion for ancestral sampling')
 
-    # hip_graph = True: the whole S-step sampling loop of CFG:683-707 (every kernel of every denoise step, on however many
-    # HIP streams cfg_mode uses) is captured ONCE per (shapes, cond_scale, weight version) into a HIP graph and replayed:
-    # one host call per sample() instead of ~660 launches per denoise step from Python.  Same kernels, same order, same
-    # device RNG stream (the Philox offsets are graph inputs): results are bitwise those of the eager path.  Off by
-    # default (the first call pays an eager warm-up and the capture); bench.py switches it on.
+    # hip_graph = True: ONE denoise step of the sampling loop of CFG:683-707 (every kernel of it, on however many HIP
+    # streams cfg_mode uses) is captured per (shapes, cond_scale, weight version, schedule) into a HIP graph and replayed
+    # S times: the step's coefficients and its timestep come from device tables that a cursor kernel at the end of the
+    # step advances (dmh_sampler_seek), so the same ~660-node graph serves every step and any S (s_step = 250 included),
+    # the capture costs one step, and the host queues replay k + 1 while replay k runs.  The last step (no noise draw,
+    # img = x_start, CFG:693-695) is a second graph in the same memory pool.  Same kernels, same order, same device RNG
+    # stream (the Philox offsets are graph inputs): results are bitwise those of the eager path, the capturing call
+    # included (the RNG state is restored after the eager warm-up).  Off by default; bench.py switches it on.
     hip_graph = False
 
     @torch.no_grad()
@@ -328,37 +331,73 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
     def _sample_graphed(self, classes, rgb_flow, flow, mask, shape, cond_scale):
         eng = self.model._engine
         eng.ensure_prepared()
+        host = self._host()                                  # (host mirrors cached before any capture)
+        device = classes.device
+        clip = True                                          # ddim_sample's clip_denoised default, as sample() calls it
+        # everything that is baked into the captured launches or into the step tables
         key = (tuple(shape), tuple(rgb_flow.shape), float(cond_scale), self.model.cfg_mode, int(self.model.stream_splits),
-               bool(self.model.dedup_dropped_rows), eng._sig, self.sampling_timesteps, self.objective,
-               str(classes.device))
+               bool(self.model.dedup_dropped_rows), float(self.model.cond_drop_prob), eng._sig, self.sampling_timesteps,
+               self.num_timesteps, self.objective, float(self.ddim_sampling_eta), clip, self.__dict__['_host_cache'][0],
+               str(device))
         st = self.__dict__.get('_graph_state')
         if st is None or st['key'] != key:
             if self.model.dedup_dropped_rows:
                 raise RuntimeError('hip_graph: dedup_dropped_rows reads the class-dropout mask on the host every step and '
                                    'cannot be captured')
-            self._host()                                     # (host mirrors cached before the capture)
-            ins = [classes.clone(), rgb_flow.to(torch.float32).clone(), flow.clone(), mask.clone()]
+            steps, times = [], []
+            for time, time_next in ddim_pairs(self.num_timesteps, self.sampling_timesteps):
+                if time_next < 0:
+                    steps.append(self._step(host, time, ops.MODE_LAST, cond_scale, clip))
+                else:
+                    steps.append(self._step(host, time, ops.MODE_DDIM, cond_scale, clip,
+                                            self._ddim_coef(host, time, time_next)))
+                times.append(time)
+            assert steps[-1].mode == ops.MODE_LAST and all(s_.mode == ops.MODE_DDIM for s_ in steps[:-1])
+            table, tt, cursor, cur = ops.step_table(steps, times, device)
+            ins = [classes.clone(), rgb_flow.to(torch.float32).clone(), mask.clone()]
+            st = {'key': key, 'ins': ins, 'table': table, 'times': tt, 'cursor': cursor, 'cur': cur, 'nsteps': len(steps),
+                  'rf': torch.empty_like(ins[1]), 'img': torch.zeros(shape, device=device),
+                  'tcond': torch.zeros((shape[0],), device=device, dtype=torch.long)}
 
-            def body():
-                rf = ops.affine(ins[1], 2., -1.)
-                img, _, _ = self.ddim_sample(ins[0], rf, ins[2], ins[3], shape, cond_scale)
-                return img
-            # eager warm-up on a side stream (first-launch work: LDS attributes, side streams, weight packs), as
-            # torch.cuda.graphs asks for; it draws from the RNG like any sample() call would
-            side = torch.cuda.Stream(device=classes.device)
+            def mid():                                       # one denoise step of CFG:684-707, in place on st['img']
+                cond, null = self._network(st['img'], st['tcond'], ins[0], st['rf'], ins[2], cond_scale)
+                noise = self.rng.randn(shape, device).contiguous()
+                ops.sampler_step_dev(cur, cond, null, st['img'], noise, out=st['img'])
+                ops.sampler_seek(cursor, -1, table, tt, cur, st['tcond'])
+
+            def last():                                      # CFG:693-695 + unnormalize, CFG:709
+                cond, null = self._network(st['img'], st['tcond'], ins[0], st['rf'], ins[2], cond_scale)
+                x0 = ops.sampler_step_dev(cur, cond, null, st['img'], None)
+                return ops.affine(x0, 0.5, 0.5)
+            # eager warm-up of both bodies on a side stream (first-launch work: LDS attributes, side streams), as
+            # torch.cuda.graphs asks for; the device RNG state is put back afterwards, so the capturing call consumes
+            # exactly what an eager sample() would
+            rng_state = torch.cuda.get_rng_state(device)
+            ops.affine(ins[1], 2., -1., out=st['rf'])
+            ops.sampler_seek(cursor, 0, table, tt, cur, st['tcond'])
+            side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                body()
+                mid()
+                last()
             torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                out = body()
-            st = {'key': key, 'graph': g, 'ins': ins, 'out': out}
+            g_mid = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_mid, capture_error_mode='thread_local'):
+                mid()
+            g_last = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_last, pool=g_mid.pool(), capture_error_mode='thread_local'):
+                st['out'] = last()
+            torch.cuda.set_rng_state(rng_state, device)
+            st['graph'], st['graph_last'] = g_mid, g_last
             self.__dict__['_graph_state'] = st
-        else:
-            for dst, src in zip(st['ins'], (classes, rgb_flow, flow, mask)):
-                dst.copy_(src)
-        st['graph'].replay()
+        for dst, src in zip(st['ins'], (classes, rgb_flow, mask)):
+            dst.copy_(src)
+        ops.affine(st['ins'][1], 2., -1., out=st['rf'])      # normalize_to_neg_one_to_one, CFG:716
+        st['img'].copy_(self.rng.randn(shape, device))       # CFG:679
+        ops.sampler_seek(st['cursor'], 0, st['table'], st['times'], st['cur'], st['tcond'])
+        for _ in range(st['nsteps'] - 1):
+            st['graph'].replay()
+        st['graph_last'].replay()
         return st['out'].clone(), mask, flow
 
     @torch.no_grad()
@@ -385,9 +424,9 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
 
     @torch.no_grad()
     def p_losses(self, x_start, t, *, classes, rgb_flow, flow, mask, noise=None):
-        """CFG:770-806, FORWARD VALUE ONLY: q_sample -> UNet (class dropout p=0.5) -> flow_warp -> L1/L2 +
-        alpha_bar_t-weighted masked photometric term.  The returned scalar carries no autograd graph: backward
-        kernels / the training step are SURVEY.md §8f "next" row 1."""
+        """CFG:770-806, the loss VALUE: q_sample -> UNet (class dropout p=0.5) -> flow_warp -> L1/L2 + alpha_bar_t-weighted
+        masked photometric term.  No autograd graph is built here; ``forward`` returns a loss with a grad_fn whose
+        gradients come from the HIP backward kernels of dmhomo_amd.train (same forward, activations saved)."""
         from .ddpm import flow_warp
         squared = self.loss_fn == 'l2'
         noise = default(noise, lambda: self.rng.randn(x_start.shape, x_start.device))

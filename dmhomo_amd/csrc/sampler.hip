@@ -140,6 +140,64 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(DmhStep s, const floa
   }
 }
 
+// the step kernel with its DmhStep read from device memory (dmh_sampler_step_dev); no __restrict__ on x / img_out: the
+// replayed loop updates img in place (every element is read by the thread that writes it)
+__global__ __launch_bounds__(256) void sampler_step_dev_kernel(const DmhStep* __restrict__ sp, const float* __restrict__ mc,
+                                                               const float* __restrict__ mn, const float* x,
+                                                               const float* __restrict__ noise, float* img_out,
+                                                               float* __restrict__ x_start, float* __restrict__ pred_noise,
+                                                               int64_t n) {
+  const DmhStep s = *sp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float mo = mc[i];
+    if (mn) {
+      const float nl = mn[i];
+      mo = nl + (mo - nl) * s.cond_scale;  // CFG:410
+    }
+    const float xt = x[i];
+    float x0, pn;
+    if (s.objective == 0) {
+      pn = mo;
+      x0 = s.sqrt_recip_ac * xt - s.sqrt_recipm1_ac * pn;
+      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    } else if (s.objective == 1) {
+      x0 = mo;
+      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
+    } else {
+      x0 = s.sqrt_ac * xt - s.sqrt_1m_ac * mo;
+      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
+    }
+    float o;
+    if (s.mode == 0) {
+      o = x0 * s.c0 + s.c1 * pn + s.c2 * noise[i];
+    } else if (s.mode == 1) {
+      o = x0;
+    } else {
+      o = s.c0 * x0 + s.c1 * xt;
+      if (noise) o = o + s.c2 * noise[i];
+    }
+    img_out[i] = o;
+    if (x_start) x_start[i] = x0;
+    if (pred_noise) pred_noise[i] = pn;
+  }
+}
+
+__global__ __launch_bounds__(64) void sampler_seek_kernel(int32_t* cursor, int k, const DmhStep* __restrict__ table,
+                                                          const int64_t* __restrict__ times, int S, DmhStep* cur,
+                                                          int64_t* tcond, int B) {
+  int c = k >= 0 ? k : *cursor + 1;
+  c = c < S ? c : S - 1;
+  __syncthreads();   // every lane has read the old cursor
+  if (threadIdx.x == 0) {
+    *cursor = c;
+    *cur = table[c];
+  }
+  const int64_t t = times[c];
+  for (int i = threadIdx.x; i < B; i += 64) tcond[i] = t;
+}
+
 __global__ __launch_bounds__(256) void affine_tail_kernel(float* __restrict__ x, int C, int HW, int c0, float scale,
                                                           float shift, int64_t total) {
   const int64_t per = (int64_t)(C - c0) * HW;
@@ -261,6 +319,25 @@ extern "C" int dmh_sampler_step(const DmhStep* s, const float* model_cond, const
   hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *s, model_cond,
                      model_null, x, noise, img_out, x_start, pred_noise, n);
   DMH_CHECK_LAUNCH("dmh_sampler_step");
+  return DMH_OK;
+}
+
+extern "C" int dmh_sampler_step_dev(const DmhStep* cur_dev, const float* model_cond, const float* model_null, const float* x,
+                                    const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
+                                    void* stream) {
+  DMH_REQUIRE(cur_dev && model_cond && x && img_out && n > 0, "dmh_sampler_step_dev: bad arguments");
+  hipLaunchKernelGGL(sampler_step_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, cur_dev, model_cond,
+                     model_null, x, noise, img_out, x_start, pred_noise, n);
+  DMH_CHECK_LAUNCH("dmh_sampler_step_dev");
+  return DMH_OK;
+}
+
+extern "C" int dmh_sampler_seek(int32_t* cursor, int k, const DmhStep* table, const int64_t* times, int S, DmhStep* cur,
+                                int64_t* tcond, int B, void* stream) {
+  DMH_REQUIRE(cursor && table && times && cur && tcond && S > 0 && B > 0 && k < S, "dmh_sampler_seek: bad arguments");
+  hipLaunchKernelGGL(sampler_seek_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cursor, k, table, times, S, cur,
+                     tcond, B);
+  DMH_CHECK_LAUNCH("dmh_sampler_seek");
   return DMH_OK;
 }
 

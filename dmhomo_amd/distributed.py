@@ -71,6 +71,32 @@ def broadcast_module_(module, src=0):
         dist.broadcast(t, src=src)
 
 
+def load_on_rank0_and_broadcast(trainer, milestone, src=0):
+    """north_star's start-up: ONLY rank ``src`` reads the checkpoint from disk (``trainer.load``: online weights + EMA
+    copy, DDP:1804-1826); every other rank receives both copies over RCCL — one scatter + all-gather payload each
+    (``broadcast_module_``) — instead of N processes each loading the file (README:14, DGM/dgm_sample.py:54).
+    ``milestone`` None: nothing to load, the seeded initialisation of rank ``src`` is broadcast.  -> True if a file was read."""
+    rank = dist.get_rank() if world_size() > 1 else 0
+    loaded = False
+    if rank == src and milestone is not None:
+        trainer.load(milestone)
+        loaded = True
+    if world_size() > 1:
+        dev = next(trainer.model.parameters()).device
+        # the EMA copy gets storage of its own only when the checkpoint's EMA weights differ from the online ones: every
+        # rank has to make the same choice before the payloads travel
+        flag = torch.tensor([int(trainer.ema.ema_model is not trainer.ema.online_model), int(loaded)], device=dev)
+        dist.broadcast(flag, src=src)
+        if bool(flag[0].item()) and trainer.ema.ema_model is trainer.ema.online_model:
+            trainer.ema._own_copy()
+        broadcast_module_(trainer.model, src=src)
+        if trainer.ema.ema_model is not trainer.ema.online_model:
+            broadcast_module_(trainer.ema.ema_model, src=src)
+            trainer.ema._bump()
+        loaded = bool(flag[1].item())
+    return loaded
+
+
 def average_gradients(grads, scale):
     """training: what accelerate's DDP wrapper does for the reference at DDP:1850 — every rank ends
     with the mean over ranks of each gradient.  ``grads``: {name: tensor}, same names and shapes on every rank;

@@ -62,7 +62,8 @@ def conv_out_hw(pc, h, w):
 
 
 # launch timing of the conv kernels with HIP events on the launch stream (bench.py's roofline leg):
-# when a list, every dmh_conv2d launch appends (start_event, end_event, k, stride, B, Hout, Wout, Cin, Cout, upsample2)
+# when a list, every dmh_conv2d launch appends (start_event, end_event, k, stride, B, Hout, Wout, Cin, Cout, upsample2,
+# has GroupNorm+SiLU prologue)
 CONV_LOG = None
 
 
@@ -89,7 +90,7 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
         e0.record()
         call('dmh_conv2d', C.byref(d))
         e1.record()
-        CONV_LOG.append((e0, e1, pc.k, pc.stride, B, ho, wo, pc.c0 + pc.c1, pc.cout, pc.upsample2))
+        CONV_LOG.append((e0, e1, pc.k, pc.stride, B, ho, wo, pc.c0 + pc.c1, pc.cout, pc.upsample2, in_coef is not None))
     else:
         call('dmh_conv2d', C.byref(d))
     return (out, stats) if want_stats else out
@@ -288,9 +289,37 @@ def sampler_step(step, model_cond, model_null, x, noise, want_x_start=True, want
     return img, xs, pn
 
 
-def affine(x, scale, shift):
+def step_table(steps, times, device):
+    """device tables of a replayed sampling loop: steps (list of DmhStep, host-computed) -> (uint8 tensor holding the
+    packed structs, int64 times, int32 cursor, one-struct uint8 'current' buffer)."""
+    n = len(steps)
+    sz = C.sizeof(_lib.DmhStep)
+    arr = (_lib.DmhStep * n)(*steps)
+    raw = torch.frombuffer(bytearray(C.string_at(C.addressof(arr), n * sz)), dtype=torch.uint8).clone()
+    table = raw.to(device)
+    tt = torch.tensor(list(times), dtype=torch.int64).to(device)
+    cursor = torch.zeros((1,), dtype=torch.int32, device=device)
+    cur = torch.zeros((sz,), dtype=torch.uint8, device=device)
+    return table, tt, cursor, cur
+
+
+def sampler_seek(cursor, k, table, times, cur, tcond):
+    """k >= 0: cursor = k; k < 0: cursor += 1 (clamped); cur = table[cursor]; tcond[:] = times[cursor]."""
+    call('dmh_sampler_seek', ptr(cursor, torch.int32), int(k), ptr(table, torch.uint8), ptr(times, torch.int64),
+         times.shape[0], ptr(cur, torch.uint8), ptr(tcond, torch.int64), tcond.shape[0])
+
+
+def sampler_step_dev(cur, model_cond, model_null, x, noise, out=None):
+    """sampler_step with its DmhStep in device memory (``cur`` of step_table); out may be x (in place)."""
+    img = torch.empty_like(x) if out is None else out
+    call('dmh_sampler_step_dev', ptr(cur, torch.uint8), ptr(model_cond), ptr(model_null), ptr(x), ptr(noise), ptr(img),
+         None, None, x.numel())
+    return img
+
+
+def affine(x, scale, shift, out=None):
     x = x.contiguous()
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
     call('dmh_affine', ptr(x), ptr(y), float(scale), float(shift), x.numel())
     return y
 

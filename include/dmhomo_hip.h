@@ -208,6 +208,19 @@ int dmh_sampler_step(const DmhStep* s, const float* model_cond, const float* mod
                      const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
                      void* stream);
 
+/* The same step with its DmhStep read from DEVICE memory, for a sampling loop (CFG:683-707, DDP:647-735) that replays
+ * ONE captured denoise step from a HIP graph: the host fills `table` (one DmhStep per denoise step, host-computed as
+ * the reference computes them, CFG:697-701) and `times` once; a device cursor selects the current entry.
+ * img_out may alias x (the loop's `img = ...` in place); mode and objective are validated when the table is built. */
+int dmh_sampler_step_dev(const DmhStep* cur_dev, const float* model_cond, const float* model_null, const float* x,
+                         const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
+                         void* stream);
+/* cursor handling of that loop (one tiny launch): k >= 0: *cursor = k; k < 0: *cursor = min(*cursor + 1, S - 1); then
+ * *cur = table[*cursor] and tcond[0 .. B) = times[*cursor] (the `time_cond` tensor of CFG:684 / DDP:700).
+ * table: [S] DmhStep, times: [S] int64, cursor: int32, all device memory. */
+int dmh_sampler_seek(int32_t* cursor, int k, const DmhStep* table, const int64_t* times, int S, DmhStep* cur,
+                     int64_t* tcond, int B, void* stream);
+
 /* y = x*scale + shift elementwise (normalize / unnormalize, CFG:69-74) */
 int dmh_affine(const float* x, float* y, float scale, float shift, int64_t n, void* stream);
 /* in place on channels >= c0 of an NCHW tensor: x = x*scale + shift (flow channel remap, DDP:679,728) */

@@ -10,7 +10,9 @@ Differences from the reference script (DGM/dgm_sample.py:11-101), all forced by 
     initialisation is used (the trained DGM.pt lives on HuggingFace, README:8);
   * the loop stops after --batches batches instead of running until killed (SAMPLE:62);
   * multi-GPU: launch with torch.distributed.run instead of N hand-started processes (--gpu_nums / -i are
-    still accepted and select the data slice exactly as the reference's unused arguments did: not at all).
+    still accepted and select the data slice exactly as the reference's unused arguments did: not at all); rank 0
+    alone reads the checkpoint and broadcasts the online + EMA weights over RCCL (the reference's N processes each
+    load the file, SAMPLE:54); sampling replays one captured denoise step from a HIP graph.
 Output: traindata/<exp>/dataset/idx_<i>_rank_<r>_part_<p>_dm_cahomo_<k>k.npy — a pickled list of
 {"imgs": uint8 (B,6,H,W), "homos": float64 (B,3,3)} every 2 batches (SAMPLE:73-77), the format
 HEM/dataset/data_loader.py:123-131 consumes.
@@ -54,11 +56,14 @@ def main():
                       gradient_accumulate_every=2, ema_decay=0.995, amp=False, results_folder='results',
                       save_and_sample_every=2000, num_samples=4, augment_horizontal_flip=False, num_worker=0,
                       total_data_slice_idx=args.gpu_nums, data_slice_idx=args.i, shuffle=False)
-    if os.path.exists(os.path.join('results', f'model-{args.c}.pt')):
-        trainer.load(args.c)
-    else:
-        print(f'results/model-{args.c}.pt not found: sampling from the seeded random initialisation')
-    D.broadcast_module_(diffusion, src=0)
+    # rank 0 alone reads the checkpoint; the online and the EMA copy reach the other ranks as one RCCL payload each
+    have = os.path.exists(os.path.join('results', f'model-{args.c}.pt')) if rank == 0 else None
+    if not D.load_on_rank0_and_broadcast(trainer, args.c if have else None):
+        if rank == 0:
+            print(f'results/model-{args.c}.pt not found: sampling from the seeded random initialisation')
+    sampler = trainer.ema.ema_model                        # what Trainer.sample draws from (DDP:1960)
+    sampler.model.cfg_mode = 'streams'
+    sampler.hip_graph = True                               # one captured denoise step replayed s_step times
     out_dir = f'traindata/{args.exp}/dataset/'
     os.makedirs(out_dir, exist_ok=True)
     train_list, part = [], args.part

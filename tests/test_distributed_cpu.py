@@ -76,6 +76,56 @@ def test_world2_gloo():
     assert torch.equal(torch.tensor(u0 + u1), full.uniform(7, torch.device('cpu')))
 
 
+def _ckpt_worker(rank, world, port, q, folder):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from dmhomo_amd import distributed as D
+    from dmhomo_amd import cfg, ddpm
+    D.init_from_env('gloo')
+    torch.manual_seed(300 + rank)                      # every rank starts from different weights
+    m = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=50, sampling_timesteps=4, objective='pred_x0')
+    # only rank 0 is given the folder that holds the checkpoint: another rank touching the file would raise
+    tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=2, results_folder=folder if rank == 0 else folder + '/absent')
+    loaded = D.load_on_rank0_and_broadcast(tr, 7)
+    dig = lambda mod: float(sum(p.double().sum() for p in mod.state_dict().values()))
+    q.put((rank, loaded, tr.ema.ema_model is not tr.ema.online_model, dig(tr.model), dig(tr.ema.ema_model)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_checkpoint_is_read_by_rank0_only_and_broadcast(tmp_path):
+    """scripts/dgm_sample.py's start-up (north_star: 'RCCL-over-xGMI broadcast of UNet weights'): rank 0 alone calls
+    Trainer.load (DDP:1804-1826); the online AND the EMA copy (which differ in a trained checkpoint, and which
+    Trainer.sample reads, DDP:1960) reach rank 1 through broadcast_module_, EMA copy in storage of its own on both."""
+    from dmhomo_amd import cfg
+    def build(seed):
+        torch.manual_seed(seed)
+        m = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1)
+        return cfg.GaussianDiffusion(m, image_size=16, timesteps=50, sampling_timesteps=4, objective='pred_x0')
+    online, ema = build(1).state_dict(), build(2).state_dict()
+    e = {'initted': torch.tensor(True), 'step': torch.tensor(5)}
+    e.update({'online_model.' + k: v.clone() for k, v in online.items()})
+    e.update({'ema_model.' + k: v.clone() for k, v in ema.items()})
+    torch.save({'step': 5, 'model': online, 'opt': None, 'ema': e, 'scaler': None, 'version': '1.0.0'},
+               str(tmp_path / 'model-7.pt'))
+    want_on = float(sum(p.double().sum() for p in online.values()))
+    want_ema = float(sum(p.double().sum() for p in ema.values()))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, loaded, own, d_on, d_ema in res:
+        assert loaded and own, (rank, loaded, own)
+        assert d_on == want_on and d_ema == want_ema, (rank, d_on, want_on, d_ema, want_ema)
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no torchrun environment: the parent starts the ranks itself (README:14 /
     dgm_sample.py:13-18 start N processes by hand), relays rank 0's single JSON line and returns the children's exit

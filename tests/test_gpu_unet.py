@@ -345,37 +345,46 @@ def test_sample_bs25_s32_rows_match_bs2():
     assert torch.equal(outs[25][:2], outs[2])
 
 
-@pytest.mark.parametrize('mode', ['batched', 'streams'])
-def test_sample_hip_graph_equals_eager(mode):
-    """GaussianDiffusion.hip_graph: the whole S-step sampling loop captured into one HIP graph (the hot
-    loop CFG:683-707) replays bitwise what the eager launch sequence computes from the same device RNG state — also when
-    the inputs change between replays, and again after a weight update (re-capture on the new weight version)."""
+@pytest.mark.parametrize('mode,S,size', [('batched', 6, 32), ('streams', 6, 32), ('streams', 250, 16), ('batched', 1, 16)])
+def test_sample_hip_graph_equals_eager(mode, S, size):
+    """GaussianDiffusion.hip_graph: ONE denoise step of the sampling loop (the hot loop CFG:683-707)
+    captured into a HIP graph whose coefficients / timestep come from device tables, replayed S times (+ the last step's
+    own graph): bitwise what the eager launch sequence computes from the same device RNG state — on the capturing call
+    itself (the warm-up must not consume random numbers), when the inputs change between replays, at s_step = 250
+    (BASELINE configs[4]'s depth), and again after a weight update (re-capture on the new weight version) or a change of
+    ddim_sampling_eta (baked into the step table)."""
     from dmhomo_amd import cfg
     m, sd = make_cfg(8)
     m.cfg_mode = mode
-    d = cfg.GaussianDiffusion(m, image_size=32, timesteps=1000, sampling_timesteps=6, objective='pred_x0').to(dev())
-    _, rf, mk = _cond_inputs(3, 32, 900)
-    rf01, flow, c = g((rf + 1) / 2), g(rand((3, 2, 32, 32), 903)), g(torch.zeros(3, dtype=torch.long))
+    d = cfg.GaussianDiffusion(m, image_size=size, timesteps=1000, sampling_timesteps=S, objective='pred_x0').to(dev())
+    _, rf, mk = _cond_inputs(3, size, 900)
+    rf01, flow, c = g((rf + 1) / 2), g(rand((3, 2, size, size), 903)), g(torch.zeros(3, dtype=torch.long))
     mk = g(mk)
 
     def run(graph, seed, rf_in):
         d.hip_graph = graph
         torch.manual_seed(seed)
         img, mo, fo = d.sample(c, rf_in, flow, mk)
-        return img.clone()
+        tail = torch.rand(4, device=dev())               # the generator is left where the eager path leaves it
+        return torch.cat([img.flatten(), tail])
     eager5, eager6 = run(False, 5, rf01), run(False, 6, 1 - rf01)
-    run(True, 1, rf01)                                   # warm-up + capture (+ one replay)
-    assert torch.equal(run(True, 5, rf01), eager5)
+    assert torch.equal(run(True, 5, rf01), eager5)       # the capturing call itself
+    g0 = d.__dict__['_graph_state']['graph']
     assert torch.equal(run(True, 6, 1 - rf01), eager6)   # new inputs, new RNG state, same graph
-    assert d.__dict__['_graph_state']['graph'] is not None
+    assert torch.equal(run(True, 5, rf01), eager5)
+    assert d.__dict__['_graph_state']['graph'] is g0
+    d.ddim_sampling_eta = 0.5                            # enters the step table: a stale replay would keep eta = 1
+    e_eta = run(False, 5, rf01)
+    assert not torch.equal(e_eta, eager5) or S == 1
+    assert torch.equal(run(True, 5, rf01), e_eta)
+    d.ddim_sampling_eta = 1.
     with torch.no_grad():
         m.final_conv.bias.add_(0.25)                     # a new weight version: re-capture, not a stale replay
     e = run(False, 5, rf01)
     assert not torch.equal(e, eager5)
     g_old = d.__dict__['_graph_state']['graph']
-    run(True, 1, rf01)                                   # (the re-capture call warms up eagerly: it draws from the RNG)
-    assert d.__dict__['_graph_state']['graph'] is not g_old
     assert torch.equal(run(True, 5, rf01), e)
+    assert d.__dict__['_graph_state']['graph'] is not g_old
     d.hip_graph = False
 
 
@@ -453,6 +462,74 @@ def test_unet_stress_geometry_vs_oracle():
     worst = max(report('stress ' + k, nchw(taps[k]), rtaps[k])[1] for k in ('downs.0.2', 'mid_attn', 'ups.3.3'))
     assert worst < LAYER_REL, worst
     close_rel('stress out', out.cpu(), ref, OUT_REL)
+
+
+def test_unet_readme_geometry_256_vs_oracle():
+    """the README's inference geometry (DGM/dgm_sample.py:28-38 hard-codes image_size = 256 with dim = 64): 65 536-pixel
+    LinearAttention at the first level, 32x32 = 1024-key bottleneck attention; B = 2 (one kept, one dropped class row),
+    per-layer taps and the output against the oracle"""
+    m, sd = make_cfg(64)
+    x, rf, mk = _cond_inputs(2, 256, 800)
+    t = torch.tensor([967, 30])
+    c = torch.zeros(2, dtype=torch.long)
+    keep = torch.tensor([True, False])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rtaps, taps = {}, {}
+    with torch.no_grad():
+        ref = OU.cfg_unet_forward(sd, x, t, c, rf, mk, keep, taps=rtaps)
+    out = m._run(g(x), g(t), g(c), g(rf), g(mk), [g(keep.to(torch.uint8))], taps=taps)
+    worst = max(report('256/dim64 ' + k, nchw(taps[k]), rtaps[k])[1] for k in rtaps)
+    assert worst < LAYER_REL, worst
+    close_rel('256/dim64 out', out.cpu(), ref, OUT_REL)
+
+
+@pytest.mark.parametrize('dim,tag', [(64, 'README geometry 256x256'), (128, 'BASELINE configs[4] geometry')])
+def test_sample_256_vs_oracle(dim, tag):
+    """the sampler (not just one forward) at 256x256: dim 64 (README / dgm_sample.py) and dim 128 (configs[4]), B = 1,
+    4 DDIM steps of a T = 100 schedule (see test_sample_fullsize_vs_oracle for why not 1000 -> 4) against the oracle on
+    replayed noise; uint8 record within 1 LSB"""
+    from dmhomo_amd import cfg, ops
+    m = cfg.Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    sd = det_state_dict(shapes_of(m), 3)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    d = cfg.GaussianDiffusion(m, image_size=256, timesteps=100, sampling_timesteps=4, objective='pred_x0').to(dev())
+    B = 1
+    _, rf, mk = _cond_inputs(B, 256, 820)
+    rf01, flow, c = (rf + 1) / 2, rand((B, 2, 256, 256), 823), torch.zeros(B, dtype=torch.long)
+    torch.manual_seed(99)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rec = OD.RecordRng()
+    with torch.no_grad():
+        ref, _, _ = OD.cfg_sample(sd, OD.schedule_buffers(100, 'cosine'), c, rf01, flow, mk, image_size=256, channels=6,
+                                  sampling_timesteps=4, objective='pred_x0', rng=rec)
+    d.rng = ReplayDeviceRng(rec.draws)
+    img, _, _ = d.sample(g(c), g(rf01), g(flow), g(mk))
+    close(f'sample 256 dim {dim} ({tag})', img.cpu(), ref, rtol=0, atol=4e-4)
+    u8 = ops.to_uint8(img).cpu().numpy().astype(np.int32)
+    ru8 = (ref.numpy() * 255).astype(np.uint8).astype(np.int32)
+    assert np.abs(u8 - ru8).max() <= 1
+
+
+def test_stress_config_s250_graph_equals_eager():
+    """BASELINE configs[4] as a sampler run: dim 128, 256x256, s_step = 250 of T = 1000, 'streams' CFG mode, B = 1 —
+    250 replays of the captured denoise step give bitwise the eager loop's images; finite and inside [0, 1]"""
+    from dmhomo_amd import cfg
+    m = cfg.Unet(dim=128, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    m.load_state_dict(det_state_dict(shapes_of(m), 3))
+    m = m.to(dev())
+    m.cfg_mode = 'streams'
+    d = cfg.GaussianDiffusion(m, image_size=256, timesteps=1000, sampling_timesteps=250, objective='pred_x0').to(dev())
+    _, rf, mk = _cond_inputs(1, 256, 840)
+    rf01, flow, c = g((rf + 1) / 2), g(rand((1, 2, 256, 256), 843)), g(torch.zeros(1, dtype=torch.long))
+    outs = []
+    for graph in (False, True):
+        d.hip_graph = graph
+        torch.manual_seed(17)
+        outs.append(d.sample(c, rf01, flow, g(mk))[0].clone())
+    d.hip_graph = False
+    assert torch.isfinite(outs[0]).all() and float(outs[0].min()) >= 0 and float(outs[0].max()) <= 1
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_unet_ddp_fullsize_vs_oracle():

@@ -208,12 +208,18 @@ def test_bench_roofline_is_a_fraction_of_the_pipe_that_runs():
 
     class A:
         bs, image_size = 25, 128
-    # (e0, e1, k, stride, B, ho, wo, cin, cout, ups): two canonical 3x3 launches at 190 us, one 1x1, one sub-pixel conv
-    log = [(Ev(), Ev(0.190), 3, 1, 50, 128, 128, 64, 64, 0), (Ev(), Ev(0.190), 3, 1, 50, 128, 128, 64, 64, 0),
-           (Ev(), Ev(0.100), 1, 1, 50, 128, 128, 128, 64, 0), (Ev(), Ev(0.165), 3, 1, 50, 128, 128, 128, 64, 2)]
+    # (e0, e1, k, stride, B, ho, wo, cin, cout, ups, prologue): two canonical 3x3 launches (with the GroupNorm + SiLU
+    # prologue) at 190 us, the same shape without the prologue at 150 us, one 1x1, one sub-pixel conv
+    log = [(Ev(), Ev(0.190), 3, 1, 50, 128, 128, 64, 64, 0, True), (Ev(), Ev(0.190), 3, 1, 50, 128, 128, 64, 64, 0, True),
+           (Ev(), Ev(0.150), 3, 1, 50, 128, 128, 64, 64, 0, False),
+           (Ev(), Ev(0.100), 1, 1, 50, 128, 128, 128, 64, 0, False), (Ev(), Ev(0.165), 3, 1, 50, 128, 128, 128, 64, 2, False)]
     r = bench.roofline(log, A)
     flop = 2.0 * 9 * 64 * 64 * 128 * 128 * 50
-    assert r['launches'] == 2 and abs(r['achieved'] - flop / 0.190e-3 / 1e12) < 1e-6
+    assert r['launches'] == 3 and abs(r['achieved'] - 3 * flop / 0.530e-3 / 1e12) < 1e-6
+    assert r['same_shape_without_prologue']['launches'] == 1
+    assert abs(r['same_shape_without_prologue']['avg_launch_us'] - 150.0) < 1e-6
+    empty = bench.roofline([(Ev(), Ev(0.1), 1, 1, 50, 128, 128, 128, 64, 0, False)], A)   # no 3x3 launch: no division by 0
+    assert empty['frac'] is None and empty['achieved'] is None
     assert abs(r['peak'] - 2500.0 / 3) < 1e-9 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12 and 0 < r['frac'] < 1
     assert abs(r['executed']['frac'] - r['frac']) < 1e-12
     assert abs(r['hbm_frac_canonical'] - 419604224.0 / 190e-6 / 8e12) < 1e-9
