@@ -379,6 +379,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 mid()
+                ops.sampler_seek(cursor, len(steps) - 1, table, tt, cur, st['tcond'])   # last() runs on the last entry
                 last()
             torch.cuda.current_stream().wait_stream(side)
             g_mid = torch.cuda.CUDAGraph()

@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void sampler_step_dev_kernel(const DmhStep* __
     }
     float o;
     if (s.mode == 0) {
-      o = x0 * s.c0 + s.c1 * pn + s.c2 * noise[i];
+      o = x0 * s.c0 + s.c1 * pn;
+      if (noise) o = o + s.c2 * noise[i];   // (a DDIM entry always comes with noise; the table cannot be checked at launch)
     } else if (s.mode == 1) {
       o = x0;
     } else {
