@@ -21,7 +21,6 @@ struct ConvArgs {
   int nch0, nch1, tilesX, tilesY;
   int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
   int xcd;     // 1: workgroup ids are re-dealt so that each XCD (id % 8) walks a contiguous run of tiles (DMH_CONV_XCD)
-  int dephase; // experiment knob (DMH_CONV_DEPHASE, cycles; 0 = off): the workgroups dispatched second onto each CU start late
 };
 
 
@@ -57,11 +56,6 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
     return e ? atoi(e) : 1;
   }();
   a.xcd = xcd;
-  static const int dephase = [] {
-    const char* e = getenv("DMH_CONV_DEPHASE");
-    return e ? atoi(e) : 0;
-  }();
-  a.dephase = dephase;
   return a;
 }
 

@@ -119,17 +119,6 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   // XCD k walks the k-th contiguous run of (cout tile, sample, tile row, tile column) — vertically adjacent tiles, whose
   // halos overlap, then run at the same time on the same L2.
   int t = blockIdx.x, by = blockIdx.y;
-  if (p.dephase > 0) {
-    // experiment: the two workgroups of a CU start together and run the same program, so they
-    // stage together and then share the matrix pipe together; delaying the second 256 dispatched workgroups (the second
-    // resident one of every CU, if dispatch fills the CUs round-robin) by about half a workgroup's life puts the pairs
-    // in anti-phase for the rest of the launch (successors inherit their predecessor's end time)
-    const int lin0 = blockIdx.x + blockIdx.y * gridDim.x;
-    if (lin0 >= 256 && lin0 < 512) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.dephase) __builtin_amdgcn_s_sleep(64);
-    }
-  }
   if (p.xcd) {
     const int nb = gridDim.x, total = nb * gridDim.y, lin = t + by * nb;
     const int q = total >> 3, r = total & 7, xcd = lin & 7, local = lin >> 3;
