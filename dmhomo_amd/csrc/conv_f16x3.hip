@@ -271,7 +271,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   int e_fix = 16;
   if (stat) {
     float m = 0.f;
-    for (int i = 0; i < p.in_bound_n; ++i) m = fmaxf(m, p.in_bound[b * p.in_bound_n + i]);
+    for (int i = 0; i < p.in_bound_n; ++i) {
+      const float v = p.in_bound[b * p.in_bound_n + i];
+      m = (v < INFINITY) ? fmaxf(m, v) : INFINITY;   // +inf or NaN: no static scale for this sample (fmaxf would drop a NaN)
+    }
     const unsigned mb = __builtin_amdgcn_readfirstlane(__float_as_uint(m));
     stat = mb < 0x7f000000u;   // +inf (or NaN): the producer declined to bound this sample -> search the tiles as usual
     // + 1: a factor of two for the rounding of the bound and of the prologue's own fma

@@ -372,8 +372,16 @@ struct FuseOut {
 constexpr int YP = 68;                                  // pitch (floats) of a pixel's 64 channels in the exchange buffer
 constexpr int YX_BYTES = 4 * TP * YP * 4;               // [head][pixel][channel] partial sums: 69632 B
 
+// DMH_HX_SLOT (never the product: `make hx`, tools/experiments/hazard_hunt/) rebuilds round 2's open case: a four-float LDS
+// slot holding 1.0, written once at kernel start, read after the exchange barrier of every sub-tile and multiplied into the
+// per-thread to_out scales — a change that cannot alter a result and did, for a few pixels of some launches under load.
+#if defined(DMH_HX_SLOT) && defined(DMH_HX_LB1)
+#define DMH_QO_WAVES 1
+#else
+#define DMH_QO_WAVES 2
+#endif
 template <bool FUSE>
-__global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+__global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const uint4* __restrict__ wq,
                                                             const float* __restrict__ oscale, const float* __restrict__ ctxm,
                                                             float* __restrict__ out, int n, int C, int nblk, int tiles,
@@ -382,6 +390,10 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
   constexpr int NBUF = FUSE ? 1 : 2;
   unsigned char* tiles_lds = smem;
   float* yx = reinterpret_cast<float*>(smem + TILE_BYTES);  // FUSE only
+#ifdef DMH_HX_SLOT
+  float* hx_slot = reinterpret_cast<float*>(smem + TILE_BYTES + YX_BYTES);
+  if (FUSE && threadIdx.x == 0) st4(hx_slot, make_float4(1.f, 1.f, 1.f, 1.f));   // (the first staging barrier publishes it)
+#endif
 
   const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -633,6 +645,17 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
       const float4 oq = ld4(fo.osc_o + quad * 4), bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
       __syncthreads();
       LSTAMP(3)  // exchange write + barrier
+#ifdef DMH_HX_SLOT
+#ifdef DMH_HX_CONST
+      const float4 hx = make_float4(1.f, 1.f, 1.f, 1.f);
+#else
+      const float4 hx = ld4(hx_slot);
+#endif
+      const float4 oqx = make_float4(oq.x * hx.x, oq.y * hx.y, oq.z * hx.z, oq.w * hx.w);
+#define DMH_OQ oqx
+#else
+#define DMH_OQ oq
+#endif
       // 64 pixels x 16 channel quads: sum the heads, undo the weight scale, + bias, LayerNorm over the 64 channels (two
       // passes, as chan_layernorm_kernel), * g, + x
 #pragma unroll
@@ -641,10 +664,10 @@ __global__ __launch_bounds__(256, 2) void linattn_qo_kernel(const float* __restr
         const float* yp = yx + pl * YP + quad * 4;
         const float4 y0 = ld4(yp), y1 = ld4(yp + TP * YP), y2 = ld4(yp + 2 * TP * YP), y3 = ld4(yp + 3 * TP * YP);
         float4 v;
-        v.x = fmaf((y0.x + y1.x) + (y2.x + y3.x), oq.x, bq4.x);
-        v.y = fmaf((y0.y + y1.y) + (y2.y + y3.y), oq.y, bq4.y);
-        v.z = fmaf((y0.z + y1.z) + (y2.z + y3.z), oq.z, bq4.z);
-        v.w = fmaf((y0.w + y1.w) + (y2.w + y3.w), oq.w, bq4.w);
+        v.x = fmaf((y0.x + y1.x) + (y2.x + y3.x), DMH_OQ.x, bq4.x);
+        v.y = fmaf((y0.y + y1.y) + (y2.y + y3.y), DMH_OQ.y, bq4.y);
+        v.z = fmaf((y0.z + y1.z) + (y2.z + y3.z), DMH_OQ.z, bq4.z);
+        v.w = fmaf((y0.w + y1.w) + (y2.w + y3.w), DMH_OQ.w, bq4.w);
         float sm = (v.x + v.y) + (v.z + v.w);
         sm = row16_sum(sm);
         const float mean = sm / 64.f;
@@ -876,7 +899,11 @@ extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, c
   fo.g_out = out_ln_g;
   fo.y = y;
   fo.eps = eps;
+#ifdef DMH_HX_SLOT
+  constexpr int LDS = TILE_BYTES + YX_BYTES + 16;
+#else
   constexpr int LDS = TILE_BYTES + YX_BYTES;
+#endif
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)linattn_qo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

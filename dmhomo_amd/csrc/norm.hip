@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
     coef[(size_t)(b * 2 + 0) * C + c] = a;
     coef[(size_t)(b * 2 + 1) * C + c] = bb;
-    bmax = fmaxf(bmax, fmaf(fabsf(a), spread, fabsf(fmaf(meanf, a, bb))));
+    // (spread == +inf: the whole group declines, whatever its gains are — 0 * inf would be a NaN that fmaxf drops)
+    bmax = fmaxf(bmax, spread < INFINITY ? fmaf(fabsf(a), spread, fabsf(fmaf(meanf, a, bb))) : INFINITY);
   }
   if (bound) {
     for (int off = 32; off; off >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, off));

@@ -245,6 +245,48 @@ def test_unet_backward_full_width_ragged_vs_autograd():
     assert worst < 6e-5, worst          # measured 5.8e-6
 
 
+def test_unet_backward_config3_geometry_vs_autograd():
+    """BASELINE configs[3]'s own geometry (dim 64, 128x128; B = 2 of the 16 images a GPU holds): the HIP backward
+    (CFG:770-842 -> loss.backward(), DDP:1843-1850) against torch autograd through the oracle's forward — every parameter,
+    with one gradient per kernel family named in the log: the 7x7 init conv, a weight-standardised 3x3 conv at 128x128,
+    a LinearAttention to_qkv, a GroupNorm gain, the bottleneck attention's to_out, the final 1x1 conv"""
+    import os
+    from test_gpu_unet import make_cfg, _cond_inputs, g
+    from dmhomo_amd import train
+    from oracle import unet as OU
+    m, sd = make_cfg(64)
+    B, S = 2, 128
+    x, rf, mk = _cond_inputs(B, S, 730)
+    t = torch.tensor([17, 803])
+    c = torch.zeros(B, dtype=torch.long)
+    keep = torch.tensor([True, False])
+    dout = rand((B, 6, S, S), 731) * (1.0 / (6 * S * S))          # the scale of d(mean loss)/d(out)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    sdd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    out_ref = OU.cfg_unet_forward(sdd, x, t, c, rf, mk, keep)
+    pnames = [k for k, _ in m.named_parameters()]
+    ref = dict(zip(pnames, torch.autograd.grad(out_ref, [sdd[k] for k in pnames], dout, allow_unused=True)))
+    ut = train.UnetTrain(m)
+    out, saved = ut.forward(g(x), g(t), g(c), g(rf), g(mk), g(keep))
+    assert _rel('unet64 @128 train fwd', out, out_ref.detach()) < 2e-4
+    got = ut.backward(saved, g(dout))
+    named = ('init_conv.weight', 'downs.0.0.block1.proj.weight', 'downs.0.2.fn.fn.to_qkv.weight',
+             'downs.0.1.block2.norm.weight', 'mid_attn.fn.fn.to_out.weight', 'final_conv.weight')
+    worst, errs = 0.0, {}
+    for k in pnames:
+        if ref[k] is None:
+            continue
+        scale = ref[k].double().abs().max().clamp_min(1e-30)
+        r = ((got[k].double().cpu().reshape(ref[k].shape) - ref[k].double()).abs().max() / scale).item()
+        errs[k] = r
+        worst = max(worst, r)
+    for k in named:
+        print(f'[parity] unet64 @128x128 bwd {k}: rel_to_max={errs[k]:.3e}')
+    wk = max(errs, key=errs.get)
+    print(f'[parity] unet64 @128x128 bwd: {len(errs)} parameter gradients, worst rel_to_max={worst:.3e} ({wk})')
+    assert worst < 1e-4, (worst, wk)
+
+
 def test_unet_backward_vs_autograd():
     """the whole conditional UNet (CFG:412-466), tiny geometry: forward with saved activations + backward on the HIP
     kernels against torch autograd through the oracle's functional forward in fp64 — every parameter's gradient"""

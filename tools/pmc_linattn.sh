@@ -1,11 +1,11 @@
 # rocprofv3 PMC evidence for the fused LinearAttention at the 128x128 level (C = 64, B = 50 rows: linattn_kv_kernel<2>,
 # linattn_qo_kernel<true>): matrix-pipe share, clock, HBM bytes.  Every counter pass is its own run with --kernel-trace only.
-#   gpurun -- bash tools/pmc_linattn.sh ; then  cp gpurun_out/pmc_la/r0N_pmc_linattn.json profiles/
+#   gpurun -- bash tools/pmc_linattn.sh ; then  cp gpurun_out/pmc_la/r03_pmc_linattn.json profiles/
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_la
 rm -rf $O && mkdir -p $O
-B="python3 $R/tools/linattn_bench.py"
+B="python3 $R/tools/linattn_bench.py --only 0"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU --output-format csv -d $O/sq -o p -- $B > $O/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $B > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $B > $O/write.log 2>&1
