@@ -18,6 +18,8 @@
 //          scale, two pieces) of the 16x16x32 MFMAs that contract over the pixels — no lane movement between the GEMMs;
 //   pass 2 multiplies channels x pixels (q^T): its accumulators (lane = pixel, registers = d), softmaxed and split, are
 //          the B operand of out^T = ctx^T q^T, whose A operand (the head's context) is split once per workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -112,6 +114,164 @@ struct Stager {
     }
     __syncthreads();
     return tile;
+  }
+  __device__ __forceinline__ float inv_scale() const { return inv_sc; }
+};
+
+// ---- RingStager (round 3, the C == 64 kernels): raw x reaches the workgroup by LDS-DMA, several chunks ahead.
+// Round 2 staged from registers one 32-channel chunk ahead: 8 KB in flight per workgroup, 16 KB per CU — by Little's law
+// ~2 TB/s for the whole chip at the ~2 us a loaded HBM round trip takes, which is what the two passes reached once the
+// benchmark stopped re-reading a cache-resident input (profiles/r03a_pmc_linattn.json: 1.3 / 1.85 TB/s algorithmic at
+// traffic_over_algorithmic 1.18 / 1.07; round 2's figures came from a 210 MB tensor that lived in the Infinity Cache).  A
+// chunk's matrix work is 0.3-0.5 us, so every second chunk waited for a whole round trip.  Here a unit = one chunk of one
+// sub-tile ([64 pixels][32 channels] fp32 = 8 KB; unit u = sub-tile u / 2, chunk u % 2) is fetched by
+// global_load_lds_dwordx4 — 8 pieces of 1 KB (8 pixels x 128 B), two per wave, no VGPRs, counted on vmcnt — into a ring of
+// RD units, RD - 1 units ahead (40 KB in flight per workgroup at RD = 6), with the sub-tile's 64 (mean, rstd) pairs
+// (global_load_lds_dword, 16 pixels per wave) in front of its first unit.  The staging pass reads the raw unit from LDS
+// (pixel pitch 128 B: the 16-lane service groups of ds_read_b128 fall on distinct banks), applies LayerNorm and the fp16
+// split exactly as Stager does, and writes the staged tile.  One raw s_barrier per chunk serves three purposes: the staged
+// tile is written, every wave's pieces of the NEXT unit have landed (each wave waits for its own with a counted vmcnt in
+// front of the barrier — a __syncthreads() would drain the DMA that must stay in flight), and the unit just read is free
+// for the DMA of unit u + RD.  No compiler-visible vector-memory load is left in the loop (hipcc would wait vmcnt(0) for
+// it and drain the ring): the LayerNorm gains sit in registers, the statistics come through the ring.
+// s_barrier without __syncthreads()'s fences (which would wait vmcnt(0) and drain the LDS-DMA that must stay in flight).
+// The intrinsic is declared as touching no memory, so hipcc may move LDS accesses across it: the empty asm statements pin
+// them (round 3: without the second one the fragment reads of the next unit were free to move above the barrier wherever no
+// DMA issue followed it — the last RD units of every workgroup — and the kernel computed from half-written tiles whenever a
+// neighbouring kernel skewed the waves: tests/test_gpu_soak.py, 58 of 60 launches).
+__device__ __forceinline__ void dmh_raw_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int RD>
+struct RingStager {
+  static constexpr int UNIT = TP * KC * 4;            // 8192
+  static constexpr int STATS_TILES = RD / 2 + 1;      // sub-tiles whose statistics may be in the ring at once
+  static constexpr int BYTES = RD * UNIT + STATS_TILES * TP * 8;
+  const float* xb;
+  const float* stats_b;
+  int n, p0w, U;               // pixels per sample, first pixel of the workgroup, units of the workgroup (even)
+  int c4, pix0, lane, wave;
+  unsigned char* ring;
+  unsigned ring_lds;
+  float4 gq[2];
+  float mean[2], rstd[2];
+  bool ok[2];
+  float sc, inv_sc;
+  int seq = 0;
+
+  __device__ __forceinline__ void init(const float* x_b, const float* stats_b_, const float* g, int n_, int p0w_, int tiles,
+                                       unsigned char* ring_) {
+    xb = x_b;
+    stats_b = stats_b_;
+    n = n_;
+    p0w = p0w_;
+    const int left = (n - p0w + TP - 1) / TP;
+    U = 2 * (left < tiles ? left : tiles);
+    lane = threadIdx.x & 63;
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c4 = threadIdx.x & 7;
+    pix0 = threadIdx.x >> 3;
+    ring = ring_;
+    ring_lds = (unsigned)(size_t)ring_;
+    float m = 0.f;
+    m = fmaxf(fabsf(g[lane]), 0.f);                   // C == 64: one gain per lane
+#pragma unroll
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    const float bound = m * 8.0f;                     // sqrt(64) * max |g|  (Stager::init_scale)
+    const int e = min(max((int)(__builtin_amdgcn_readfirstlane(__float_as_uint(bound)) >> 23) & 0xff, 16), 254);
+    sc = __uint_as_float((unsigned)(268 - e) << 23);
+    inv_sc = __uint_as_float((unsigned)(e - 14) << 23);
+    gq[0] = ld4(g + c4 * 4);
+    gq[1] = ld4(g + KC + c4 * 4);
+  }
+  __device__ __forceinline__ void glds(const void* src, unsigned lds_dst, bool x4) {
+    unsigned keep;
+    if (x4)
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+    else
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+  }
+  // unit u (< U): [its sub-tile's statistics, when it is the sub-tile's first chunk,] then the wave's two pieces
+  __device__ __forceinline__ void issue_unit(int u) {
+    const int tile = u >> 1, ch = u & 1;
+    const int p0 = p0w + tile * TP;
+    if (ch == 0) {   // statistics of the sub-tile: wave w brings the (mean, rstd) of its pixels 16 w .. 16 w + 15 (128 B)
+      const int fl = min((p0 + wave * 16) * 2 + (lane & 31), 2 * n - 1);      // clamped; pixels beyond n are masked later
+      if (lane < 32) glds(stats_b + fl, ring_lds + RD * UNIT + (tile % STATS_TILES) * (TP * 8) + wave * 128, false);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int piece = wave * 2 + j;                 // pixels 8 * piece .. + 7 of the unit, 128 B each
+      const int pc = min(p0 + piece * 8 + (lane >> 3), n - 1);
+      glds(xb + (size_t)pc * 64 + ch * KC + (lane & 7) * 4, ring_lds + (u % RD) * UNIT + piece * 1024, true);
+    }
+  }
+  // pieces this wave has issued AFTER those of unit v (v + 1 .. last issued), bounded below: a smaller count only waits longer
+  __device__ __forceinline__ void wait_unit(int v, int last_issued) {
+    const int k = min(last_issued, U - 1) - v;        // younger units
+    // 2 pieces per unit + 1 statistics piece per sub-tile start among them (at least k / 2)
+    if (k >= 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if (k == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    else if (k == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (k == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __device__ __forceinline__ void prime() {
+    static_assert(RD == 6, "wait_unit counts for a ring of six units");
+    for (int u = 0; u < RD && u < U; ++u) issue_unit(u);
+    wait_unit(0, RD - 1);
+    dmh_raw_barrier();
+  }
+  // stage unit `seq` into one of the two LDS tiles; returns the tile
+  __device__ __forceinline__ unsigned char* stage(unsigned char* tiles, const int ch) {   // ch == seq & 1 (a constant at the call)
+    const int u = seq++;
+    unsigned char* tile = tiles + ch * TILE_BYTES;
+    const unsigned char* raw = ring + (u % RD) * UNIT;
+    if (ch == 0) {
+      const int p0 = p0w + (u >> 1) * TP;
+      const float* st = reinterpret_cast<const float*>(ring + RD * UNIT + ((u >> 1) % STATS_TILES) * (TP * 8));
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float2 mr = *reinterpret_cast<const float2*>(st + (pix0 + 32 * i) * 2);
+        mean[i] = mr.x;
+        rstd[i] = mr.y;
+        ok[i] = p0 + pix0 + 32 * i < n;
+      }
+    }
+    const float4 gv = ch ? gq[1] : gq[0];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 x = *reinterpret_cast<const float4*>(raw + (pix0 + 32 * i) * 128 + c4 * 16);
+      if (ok[i]) {
+        x.x = (x.x - mean[i]) * rstd[i] * gv.x;  // exactly chan_layernorm_kernel's expression
+        x.y = (x.y - mean[i]) * rstd[i] * gv.y;
+        x.z = (x.z - mean[i]) * rstd[i] * gv.z;
+        x.w = (x.w - mean[i]) * rstd[i] * gv.w;
+      } else {
+        x = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      uint2 h1, h2;
+      dmh_split2(x.x, x.y, sc, h1.x, h2.x);
+      dmh_split2(x.z, x.w, sc, h1.y, h2.y);
+      unsigned char* dst = tile + (pix0 + 32 * i) * PITCH + c4 * 8;
+      *reinterpret_cast<uint2*>(dst) = h1;
+      *reinterpret_cast<uint2*>(dst + 64) = h2;
+    }
+    return tile;
+  }
+  // after stage() of unit u: the staged tile is written (and the reads of raw unit u are back: the writes depend on them);
+  // wait for this wave's pieces of unit u + 1, ONE barrier, then refill the slot every wave has just finished reading.
+  __device__ __forceinline__ void sync() {
+    const int u = seq - 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (u + 1 < U) wait_unit(u + 1, u - 1 + RD);
+    dmh_raw_barrier();
+    if (u + RD < U) issue_unit(u + RD);
   }
   __device__ __forceinline__ float inv_scale() const { return inv_sc; }
 };
@@ -337,6 +497,220 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
       for (int db = 0; db < 2; ++db) ctx[eb][db] += t[eb][db] * inv_v;
   }
 
+  float* out = partial + ((size_t)(b * nsplit + sp) * 4 + h) * LA_PART;
+  if (kg == 0) {
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      out[db * 16 + l15] = m_run[db] * 0.693147180559945309f;   // back to the natural domain the merge works in
+      out[32 + db * 16 + l15] = s_run[db];
+    }
+  }
+  // ctx[d][e] row-major: this lane's four consecutive e of column d are one 16 B piece
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+      st4(out + 64 + (db * 16 + l15) * 32 + eb * 16 + 4 * kg,
+          make_float4(ctx[eb][db][0], ctx[eb][db][1], ctx[eb][db][2], ctx[eb][db][3]));
+}
+
+__global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                            const float* __restrict__ g, const uint4* __restrict__ wkv,
+                                                            const float* __restrict__ oscale, float* __restrict__ partial,
+                                                            int n, int C, int nsplit, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tiles_lds = smem;  // two staging tiles, then the raw ring
+  constexpr int RES = 2;            // C == 64: both chunks' weight fragments stay in registers
+
+  const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+
+  RingStager<6> st;
+  st.init(x + (size_t)b * n * C, stats + (size_t)b * n * 2, g, n, sp * tiles * TP, tiles, smem + 2 * TILE_BYTES);
+  const int nch = 2;
+
+  const uint4* wb = wkv + (size_t)h * nch * (8 * 64) + lane;
+  float osc[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) osc[nb] = oscale[(h * 4 + nb) * 16 + l15];
+
+  // running state over the sub-tiles: per column d = db*16 + l15 (lanes; the maxima in the base-2 domain), and the context
+  // TRANSPOSED, ctx[eb][db] = block (rows e = eb*16 + 4*kg + r, columns d = db*16 + l15): the softmax rescale of a column d
+  // is then one multiplier per lane (round 2, late; with rows d it took eight cross-lane reads per sub-tile)
+  float m_run[2] = {-INFINITY, -INFINITY}, s_run[2] = {0.f, 0.f};
+  float4v ctx[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ctx[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  uint4 wres[RES ? RES : 1][8];
+  if (RES) {
+#pragma unroll
+    for (int ch = 0; ch < RES; ++ch)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) wres[ch][i] = wb[(size_t)(ch * 8 + i) * 64];
+  }
+  // every compiler-visible vector-memory load of the kernel is consumed HERE, in front of the ring: hipcc cannot see the
+  // LDS-DMA, and a load result first used inside the loop would get an s_waitcnt vmcnt(0) there that drains the ring on
+  // every unit (it did: the LayerNorm gains)
+#pragma unroll
+  for (int ch = 0; ch < RES; ++ch)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(wres[ch][i].x), "v"(wres[ch][i].y), "v"(wres[ch][i].z), "v"(wres[ch][i].w));
+  asm volatile("" ::"v"(st.gq[0].x), "v"(st.gq[0].y), "v"(st.gq[0].z), "v"(st.gq[0].w), "v"(st.gq[1].x), "v"(st.gq[1].y),
+               "v"(st.gq[1].z), "v"(st.gq[1].w), "v"(osc[0]), "v"(osc[1]), "v"(osc[2]), "v"(osc[3]));
+  st.prime();
+  for (int tI = 0; tI < tiles; ++tI) {
+    const int p0 = (sp * tiles + tI) * TP;
+    if (p0 >= n) break;
+    float4v acc[4][4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = float4v{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+      const unsigned char* tile = st.stage(tiles_lds, ch);
+      st.sync();
+      half8 a[4][2];
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+          a[mb][pl] = *reinterpret_cast<const half8*>(tile + (mb * 16 + l15) * PITCH + kg * 16 + pl * 64);
+#define LA_TERM(pl, bexpr)                                                                          \
+  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) \
+      acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
+      LA_TERM(1, __builtin_bit_cast(half8, wres[ch][nb * 2]))
+      LA_TERM(0, __builtin_bit_cast(half8, wres[ch][nb * 2 + 1]))
+      LA_TERM(0, __builtin_bit_cast(half8, wres[ch][nb * 2]))
+#undef LA_TERM
+    }
+    const float inv_s = st.inv_scale();
+
+    // ---- k, v of this sub-tile: acc[mb][nb][r] = value(pixel p0 + mb*16 + 4*kg + r, column nb*16 + l15)
+    // (1 / block scale and the weight column's 2^-k are both powers of two: one exact multiplier)
+    const bool full = p0 + TP <= n;  // uniform: only the last sub-tile of a ragged image masks its pixels
+    // (round 3: the column's multiplier k * log2(e) — 1 / block scale, the weight column's 2^-k, log2(e): positive — is
+    //  applied inside the exponential's fma; the maximum is taken over the raw accumulators and scaled once)
+    float m_new[2], kks[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      kks[db] = inv_s * osc[db] * 1.44269504088896341f;
+      float m = -INFINITY;
+      if (!full) {
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (!(p0 + mb * 16 + 4 * kg + r < n)) acc[mb][db][r] = -INFINITY;   // 2^(-inf) = 0 below
+      }
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, acc[mb][db][r]);
+      m = rows_max(m) * kks[db];
+      m_new[db] = fmaxf(m_run[db], m);
+    }
+    // rescale the running context columns by 2^(m_run - m_new): column d = this lane
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const float fcol = __builtin_amdgcn_exp2f(m_run[db] - m_new[db]);  // 0 on the first sub-tile (m_run = -inf)
+      s_run[db] *= fcol;
+      ctx[0][db] *= fcol;
+      ctx[1][db] *= fcol;
+      m_run[db] = m_new[db];
+    }
+    // ---- ctx[d][e] += sum_n p[n][d] v[n][e] on the fp16 matrix cores (round 2; round 1: 64 fp32 16x16x4 MFMAs per sub-tile,
+    // which execute on the vector ALUs).  The accumulator layout is the operand layout: lane (l15, kg) holds column l15
+    // (d for p, e for v) of the pixels mb*16 + 4*kg + r, and K slot 8*kg + j of step s is pixel (2s + (j >> 2))*16 + 4*kg
+    // + (j & 3) for A and B alike.  p = 2^(k - m) lies in [0, 1]: * 2^10, split; v: one power-of-two scale per wave and
+    // sub-tile, split.  v is the A operand: D rows = e, D columns = d = l15 (the transposed context, see above).
+    half8 p1[2][2], p2[2][2], v1[2][2], v2[2][2];  // [block][K step]
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pv[j] = __builtin_amdgcn_exp2f(fmaf(acc[2 * ks + (j >> 2)][db][j & 3], kks[db], -m_new[db]));  // 2^-inf = 0 beyond n
+          s += pv[j];
+        }
+        dmh_split8(pv, 1024.f, p1[db][ks], p2[db][ks]);
+      }
+      s = rows_sum(s);
+      s_run[db] += s;
+    }
+    // v: one power-of-two scale for the wave's 64 pixels x 32 columns (fp16 pieces are floating point: a block-wide
+    // scale costs range, not precision — as in the conv kernels), so the product is unscaled by one uniform factor
+    // (round 3: 1 / block scale and the weight column's 2^-k — powers of two — ride on the split's multiplier, which is exact;
+    //  the block maximum is taken over the raw accumulators, one multiply per column.  The split's inline asm reads MFMA
+    //  results directly: its multiplier depends on the maximum over ALL of them, so every accumulator register has been read
+    //  by a compiler-visible instruction, behind hipcc's own hazard padding, before the asm can start)
+    unsigned mx = 0u;
+    float kv2[2];
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+      // (pixels beyond n were staged as zeros, so their v is exactly 0 without a mask)
+      kv2[eb] = inv_s * osc[2 + eb];
+      unsigned mr = 0u;
+#pragma unroll
+      for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mr = max(mr, absbits(acc[mb][2 + eb][r]));
+      mx = max(mx, absbits(__uint_as_float(mr) * kv2[eb]));
+    }
+    mx = wave_max_u32(mx);
+    const int exv = min(max((int)(mx >> 23), 32), 254);
+    const float scv = __uint_as_float((unsigned)(268 - exv) << 23);         // block maximum * scv in [2^14, 2^15)
+    const float inv_v = __uint_as_float((unsigned)(exv - 14 - 10) << 23);   // 1 / scv, and the 2^10 of p
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb) {
+      const float sv = scv * kv2[eb];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        float vv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vv[j] = acc[2 * ks + (j >> 2)][2 + eb][j & 3];
+        dmh_split8(vv, sv, v1[eb][ks], v2[eb][ks]);
+      }
+    }
+    float4v t[2][2];  // [eb][db]: four independent chains, term by term; A = v (rows e), B = p (columns d)
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+        t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2[eb][0], p1[db][0], float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v2[eb][1], p1[db][1], t[eb][db], 0, 0, 0);
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1[eb][st2], p2[db][st2], t[eb][db], 0, 0, 0);
+#pragma unroll
+    for (int st2 = 0; st2 < 2; ++st2)
+#pragma unroll
+      for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          t[eb][db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1[eb][st2], p1[db][st2], t[eb][db], 0, 0, 0);
+#pragma unroll
+    for (int eb = 0; eb < 2; ++eb)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) ctx[eb][db] += t[eb][db] * inv_v;
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no LDS-DMA may still be on its way when the workgroup ends)
   float* out = partial + ((size_t)(b * nsplit + sp) * 4 + h) * LA_PART;
   if (kg == 0) {
 #pragma unroll
@@ -807,7 +1181,25 @@ extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, con
   const int tiles = fused_tiles(B, n), nsplit = cdiv(cdiv(n, TP), tiles);
   const uint4* wkv = reinterpret_cast<const uint4*>(wpack + (int64_t)C * 128);
   const float* osc_kv = wpack + (int64_t)C * 384 + 128;
-  if (C == 2 * KC)
+  static const int use_ring = [] {   // development knob for same-box A/Bs: DMH_LA_RING=0 -> round 2's register staging
+    const char* e = getenv("DMH_LA_RING");
+    return e ? atoi(e) : 1;
+  }();
+  if (C == 2 * KC && use_ring) {
+    static const int lds_pad = [] {   // experiment knob: extra LDS per workgroup (> 10 KB: one workgroup per CU)
+      const char* e = getenv("DMH_LA_LDS_PAD");
+      return e ? atoi(e) : 0;
+    }();
+    const int LDS = 2 * TILE_BYTES + RingStager<6>::BYTES + lds_pad;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)linattn_kv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      DMH_REQUIRE(e == hipSuccess, "dmh_linattn_fused_context: cannot raise the LDS limit");
+      attr = true;
+    }
+    hipLaunchKernelGGL(linattn_kv_ring_kernel, dim3(B * nsplit), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wkv,
+                       osc_kv, partial, n, C, nsplit, tiles);
+  } else if (C == 2 * KC)
     hipLaunchKernelGGL(linattn_kv_kernel<2>, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
                        wkv, osc_kv, partial, n, C, nsplit, tiles);
   else

@@ -6,7 +6,11 @@ preceding instructions:
   RAW   a source register written by an MFMA (vDst)
   WAW   the destination written by an MFMA
   WAR-C the destination read as SrcC by an MFMA whose vDst is a different register range
-and for every MFMA: A/B/C sources written by an inline-asm VALU less than NOPS wait states earlier.
+and for every MFMA: A/B/C sources written by an inline-asm VALU less than NOPS wait states earlier;
+  TRANS a source written by a transcendental instruction (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos) in the
+        instruction directly in front (gfx940+ forwards a transcendental result one wait state late; hipcc pads its own
+        consumers, not an inline-asm one).
+Run by tests/test_isa_hazards.py over every source that contains inline-asm vector instructions.
 """
 import re, sys
 WINDOW = 19   # the longest wait the gfx950 tables ask for (16-pass MFMA result -> VALU)
@@ -46,6 +50,8 @@ def scan(path):
             d = regs(ops[0]); srcs = set()
             for o in ops[1:]: srcs |= regs(o)
             if 'mixhi' in op or 'mixlo' in op: srcs |= d
+            if hist and hist[-1].get('trans') and hist[-1]['dst'] & srcs:
+                print(f'{kern}:{ln}: asm {op} reads v{sorted(hist[-1]["dst"] & srcs)} written by the transcendental instruction directly in front (line {hist[-1]["ln"]})'); n_find += 1
             dist = 0
             for h in reversed(hist):
                 if h['kind'] == 'mfma':
@@ -57,7 +63,8 @@ def scan(path):
             hist.append(dict(kind='valu', dst=d, asm=True, ln=ln, waits=1))
         else:
             d = regs(ops[0]) if ops and op.startswith(('v_', 'ds_read', 'global_load', 'buffer_load')) else set()
-            hist.append(dict(kind='other', dst=d, asm=False, ln=ln, waits=waits))
+            trans = (not in_asm) and op.split('_e')[0] in ('v_exp_f32', 'v_log_f32', 'v_rcp_f32', 'v_rsq_f32', 'v_sqrt_f32', 'v_sin_f32', 'v_cos_f32')
+            hist.append(dict(kind='other', dst=d, asm=False, ln=ln, waits=waits, trans=trans))
         if len(hist) > 4 * WINDOW: hist = hist[-2 * WINDOW:]
     return n_find
 if __name__ == '__main__':
