@@ -20,8 +20,12 @@ c_int = C.c_int
 c_float = C.c_float
 
 
+ABI_VERSION = 300          # include/dmhomo_hip.h: DMH_ABI_VERSION
+
+
 class DmhConv(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('src0', 'src1', 'wpack', 'bias', 'in_coef', 'res', 'res_coef', 'out',
+    _fields_ = [('struct_size', C.c_uint64)] + \
+               [(n, C.c_void_p) for n in ('src0', 'src1', 'wpack', 'bias', 'in_coef', 'res', 'res_coef', 'out',
                                           'stats')] + \
                [(n, C.c_int32) for n in ('B', 'Hin', 'Win', 'C0', 'C1', 'Cout', 'KH', 'KW', 'stride', 'upsample2')] + \
                [('in_bound', C.c_void_p), ('in_bound_n', C.c_int32)]
@@ -154,6 +158,10 @@ def lib():
             fn = getattr(h, name)          # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        got = int(h.dmh_version())
+        if got != ABI_VERSION:
+            raise DmhError(f'{LIB_PATH} reports ABI version {got}, this binding was written against {ABI_VERSION} '
+                           f'(include/dmhomo_hip.h): rebuild the library with `make -C dmhomo_amd/csrc`')
         _lib = h
     return _lib
 

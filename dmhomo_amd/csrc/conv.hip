@@ -399,7 +399,10 @@ extern "C" int dmh_ws_standardize(const float* w, float* w_out, int Cout, int K,
 }
 
 extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
-  DMH_REQUIRE(d && d->src0 && d->wpack && d->out, "dmh_conv2d: null pointer");
+  DMH_REQUIRE(d && d->struct_size == sizeof(DmhConv),
+              "dmh_conv2d: DmhConv.struct_size is %llu, this library's DmhConv has %llu bytes (header / library mismatch)",
+              d ? (unsigned long long)d->struct_size : 0ull, (unsigned long long)sizeof(DmhConv));
+  DMH_REQUIRE(d->src0 && d->wpack && d->out, "dmh_conv2d: null pointer");
   DMH_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->C0 > 0 && d->Cout > 0, "dmh_conv2d: bad shape");
   DMH_REQUIRE(d->C0 % 4 == 0 && (!d->src1 || d->C1 % 4 == 0),
               "dmh_conv2d: input channels must be a multiple of 4 (got %d, %d)", d->C0, d->C1);

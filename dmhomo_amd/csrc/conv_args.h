@@ -197,7 +197,7 @@ struct EpilogueRows {
     }
   }
 
-  // Variant for the WM x WN wave grids of conv_bf16x3.hip (each wave: 64 pixels x its own 64-channel block).
+  // Variant for the WM x WN wave grids of conv_f16x3.hip (each wave: 64 pixels x its own 64-channel block).
   // Stat tiles are 8 rows x 16 columns (= two waves along M) whatever the workgroup tile, so the tile count
   // does not depend on Cout: stats[b][stat tile][Cout][2] with stat tile = (ty * TH/8 + g) * tilesX + tx.
   template <int WM, int WN, int TH>

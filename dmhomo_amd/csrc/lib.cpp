@@ -14,4 +14,4 @@ void dmh_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* dmh_last_error(void) { return g_err; }
-extern "C" int dmh_version(void) { return 100; }
+extern "C" int dmh_version(void) { return DMH_ABI_VERSION; }

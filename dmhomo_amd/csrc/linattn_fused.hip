@@ -792,7 +792,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
   // The context of a head is fixed for the workgroup: one block maximum over its 1024 values, split once.
   float osc[2][4];
   half8 c1[2], c2[2];
-  float inv_c;
+  float inv_c, mo = 1.f, inv_o = 1.f;
   {
     const float* cb = ctxm + (size_t)(b * 4 + h) * 1024;
     float cv[2][8];
@@ -815,6 +815,22 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
     inv_c = __uint_as_float((unsigned)(ex - 14 - 17) << 23);  // 1 / scc, and the 2^17 q' carries (below)
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb) dmh_split8(cv[eb], scc, c1[eb], c2[eb]);
+    if (FUSE) {
+      // STATIC block scale of the attention output (round 3; round 2 tried it, c44f485, and took it back, 25ebbcb, because it
+      // fed MFMA results straight into the split's inline asm — see the wait states in front of the split below):
+      // |o[e]| = |sum_d ctx[d][e] q'[d]| <= max|ctx| * sum_d q'[d] = max|ctx| * scale, so the scale is known per workgroup;
+      // taken over ALL FOUR heads it is the same for every wave, and its inverse rides on the per-channel to_out unscale
+      // where the heads are summed: no per-pixel maximum (32 and/max + a cross-lane reduction per 16 pixels), no
+      // per-accumulator multiply before the split (32) or after the to_out product (64) any more.
+      unsigned* xm = reinterpret_cast<unsigned*>(yx);
+      if (lane == 0) xm[h] = mx;
+      __syncthreads();
+      const unsigned ma = max(max(xm[0], xm[1]), max(xm[2], xm[3]));
+      const float bo = __uint_as_float(ma) * scale;
+      const int exo = min(max((int)(__float_as_uint(bo) >> 23) + 1, 16), 254);   // + 1: sum q' = scale (1 + rounding)
+      mo = inv_c * __uint_as_float((unsigned)(268 - exo) << 23);                 // accumulator units -> o * 2^(141 - exo)
+      inv_o = __uint_as_float((unsigned)(exo - 14) << 23);
+    }
   }
   float* ob = out + (size_t)b * n * 128 + h * 32;
   // FUSE: to_out weight fragments of this head (A operand: rows c, K = the head's 32 channels), kept in registers
@@ -957,43 +973,47 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
 #pragma unroll
       for (int eb = 0; eb < 2; ++eb)
         ot[nbn][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1[eb], q1[nbn], ot[nbn][eb], 0, 0, 0);
+    if (FUSE) {
+      // The split reads the MFMA results through inline asm and writes registers hipcc is free to take from MFMA operands
+      // that have just died — its hazard recognizer pads neither side of an asm statement.  So: 8 wait states behind the
+      // last v_mfma_f32_16x16x32_f16 (4 passes), pinned to every accumulator register the splits read; then ALL four
+      // splits; then the 48 to_out MFMAs with no asm statement between them (tests/test_isa_hazards.py scans the result;
+      // split-by-split, the second split's destinations were the third-last MFMA's SrcC: round 2's fault, commit 25ebbcb)
+      asm volatile("s_nop 7"
+                   : "+v"(ot[0][0]), "+v"(ot[0][1]), "+v"(ot[1][0]), "+v"(ot[1][1]), "+v"(ot[2][0]), "+v"(ot[2][1]),
+                     "+v"(ot[3][0]), "+v"(ot[3][1]));
+      half8 h1[4], h2[4];
 #pragma unroll
-    for (int nbn = 0; nbn < 4; ++nbn) {
-      float4v o[2];
+      for (int nbn = 0; nbn < 4; ++nbn) {
+        // the 8 values of this lane (e = eb*16 + 4*kg + r of pixel column l15) are one K = 32 B-fragment slice, split under
+        // the workgroup's static scale (see the head of the kernel)
+        float o8[8];
 #pragma unroll
-      for (int eb = 0; eb < 2; ++eb) o[eb] = ot[nbn][eb] * inv_c;
-      if (!FUSE) {
+        for (int j = 0; j < 8; ++j) o8[j] = ot[nbn][j >> 2][j & 3];
+        dmh_split8(o8, mo, h1[nbn], h2[nbn]);
+      }
+#pragma unroll
+      for (int nbn = 0; nbn < 4; ++nbn)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) yacc[cb][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h2[nbn], float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int nbn = 0; nbn < 4; ++nbn)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) yacc[cb][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo2[cb], h1[nbn], yacc[cb][nbn], 0, 0, 0);
+#pragma unroll
+      for (int nbn = 0; nbn < 4; ++nbn)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) yacc[cb][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h1[nbn], yacc[cb][nbn], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int nbn = 0; nbn < 4; ++nbn) {
         const int pix = p0 + nbn * 16 + l15;  // column = pixel; rows e = eb*16 + 4*kg + r: four consecutive channels
         if (pix < n) {
 #pragma unroll
-          for (int eb = 0; eb < 2; ++eb)
-            st4(ob + (size_t)pix * 128 + eb * 16 + 4 * kg, make_float4(o[eb][0], o[eb][1], o[eb][2], o[eb][3]));
-        }
-      } else {
-        // the 8 values of this lane (e = eb*16 + 4*kg + r of pixel column l15) are one K = 32 B-fragment slice;
-        // block scale per pixel column (max over the column's 32 e = over the 4 kg lanes), fp16 pieces as everywhere
-        unsigned mx = 0u;
-#pragma unroll
-        for (int eb = 0; eb < 2; ++eb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) mx = max(mx, absbits(o[eb][r]));
-        mx = rows_max_u32(mx);
-        const int ex = min(max((int)(mx >> 23), 16), 254);
-        const float sc = __uint_as_float((unsigned)(268 - ex) << 23), inv = __uint_as_float((unsigned)(ex - 14) << 23);
-        half8 h1, h2;
-        {
-          float o8[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o8[j] = o[j >> 2][j & 3];
-          dmh_split8(o8, sc, h1, h2);
-        }
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          float4v t = float4v{0.f, 0.f, 0.f, 0.f};
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h2, t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo2[cb], h1, t, 0, 0, 0);
-          t = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo1[cb], h1, t, 0, 0, 0);
-          yacc[cb][nbn] = t * inv;
+          for (int eb = 0; eb < 2; ++eb) {
+            const float4v o = ot[nbn][eb] * inv_c;
+            st4(ob + (size_t)pix * 128 + eb * 16 + 4 * kg, make_float4(o[0], o[1], o[2], o[3]));
+          }
         }
       }
     }
@@ -1016,7 +1036,12 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
         const int pix = min(p0 + (tid >> 4) + 16 * i, n - 1);
         xr[i] = ld4(st.xb + (size_t)pix * 64 + quad * 4);
       }
-      const float4 oq = ld4(fo.osc_o + quad * 4), bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
+      float4 oq = ld4(fo.osc_o + quad * 4);
+      const float4 bq4 = ld4(fo.bias + quad * 4), gq4 = ld4(fo.g_out + quad * 4);
+      oq.x *= inv_o;   // 2^-k of the to_out row and 1 / (static output scale): powers of two
+      oq.y *= inv_o;
+      oq.z *= inv_o;
+      oq.w *= inv_o;
       __syncthreads();
       LSTAMP(3)  // exchange write + barrier
 #ifdef DMH_HX_SLOT

@@ -82,7 +82,7 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
         stats = _empty((B, tiles, pc.cout, 2), src0)
     if res is not None:
         assert res.shape == out.shape, (res.shape, out.shape)
-    d = _lib.DmhConv(ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
+    d = _lib.DmhConv(C.sizeof(_lib.DmhConv), ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
                      ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2,
                      ptr(in_bound), 0 if in_bound is None else in_bound.shape[1])
     if CONV_LOG is not None:

@@ -34,6 +34,9 @@ extern "C" {
 #define DMH_ELAUNCH (-2) /* hip launch error */
 
 const char* dmh_last_error(void);
+/* DMH_ABI_VERSION of the library: bumped whenever a struct layout or an entry point changes; a binding must refuse a
+ * library whose version differs from the header it was written against (dmhomo_amd/_lib.py does). */
+#define DMH_ABI_VERSION 300
 int dmh_version(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -71,6 +74,8 @@ int dmh_pack_conv_weight_up2(const float* w_oihw, float* wpack, int Cout, int C0
  * DESIGN.md 3.1).  DMH_CONV3_VARIANT=0..3 / 6 (environment, read once) selects the exact-fp32 MFMA kernels.
  * ------------------------------------------------------------------------------------- */
 typedef struct DmhConv {
+  uint64_t struct_size; /* sizeof(DmhConv) of the header the caller was built against: dmh_conv2d refuses any other value
+                           (the struct has grown between library versions; a shorter one would be read past its end) */
   const float* src0; /* NHWC [B][Hin][Win][C0] */
   const float* src1; /* NHWC [B][Hin][Win][C1] or NULL: torch.cat((src0, src1), dim=1) fused (CFG:454,457,463) */
   const float* wpack; /* dmh_pack_conv_weight image */

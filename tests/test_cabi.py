@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in header_functions():
         assert hasattr(h, name), name
     lib = _lib.lib()
-    assert lib.dmh_version() >= 100
+    assert lib.dmh_version() == _lib.ABI_VERSION == 300
 
 
 def test_pure_host_entry_points():
@@ -62,9 +62,12 @@ def test_pure_host_entry_points():
 def test_bad_arguments_use_the_error_channel():
     from dmhomo_amd import _lib
     lib = _lib.lib()
-    d = _lib.DmhConv()
+    d = _lib.DmhConv()                                   # struct_size 0: a caller built against another header
     assert lib.dmh_conv2d(ctypes.byref(d), None) == -1
-    assert b'dmh_conv2d' in lib.dmh_last_error()
+    assert b'struct_size' in lib.dmh_last_error()
+    d = _lib.DmhConv(ctypes.sizeof(_lib.DmhConv))
+    assert lib.dmh_conv2d(ctypes.byref(d), None) == -1
+    assert b'dmh_conv2d: null pointer' in lib.dmh_last_error()
     assert lib.dmh_chan_layernorm(None, None, None, None, 4, 64, 1e-5, None) == -1
     assert lib.dmh_linear(None, 0, None, None, None, 0, 1, 1, 1, 0, 0, None) == -1
 

@@ -3,7 +3,7 @@
 
 Inline asm shows up between ;;#ASMSTART / ;;#ASMEND.  For every VALU instruction inside such a block report, within WINDOW
 preceding instructions:
-  RAW   a source register written by an MFMA (vDst)
+  RAW   a source register written by an MFMA (vDst) fewer than passes + 4 wait states earlier (see need())
   WAW   the destination written by an MFMA
   WAR-C the destination read as SrcC by an MFMA whose vDst is a different register range
 and for every MFMA: A/B/C sources written by an inline-asm VALU less than NOPS wait states earlier;
@@ -13,7 +13,15 @@ and for every MFMA: A/B/C sources written by an inline-asm VALU less than NOPS w
 Run by tests/test_isa_hazards.py over every source that contains inline-asm vector instructions.
 """
 import re, sys
-WINDOW = 19   # the longest wait the gfx950 tables ask for (16-pass MFMA result -> VALU)
+WINDOW = 20   # the longest wait the gfx950 tables ask for (16-pass MFMA result -> VALU)
+def need(op):
+    """wait states between an MFMA and a VALU that reads / overwrites its vDst (or overwrites its SrcC) on gfx950: passes + 4
+    (LLVM GCNHazardRecognizer, GFX940_XDL_N_PassWriteVgprVALU*WaitStates with the gfx950 extra state).  Passes from the
+    measured issue cycles of MI355X_MICROARCH.md (4 cycles per pass): 16x16x32 16-bit -> 4, 32x32x16 16-bit and 16x16x4 f32
+    -> 8, 32x32x2 f32 -> 16; anything unknown is treated as 16 passes."""
+    if '16x16x32' in op or '16x16x16' in op or '4x4' in op: return 8
+    if '32x32x16' in op or '32x32x8' in op or '16x16x4' in op: return 12
+    return 20
 def regs(tok):
     tok = tok.strip().rstrip(',')
     m = re.match(r'-?\|?v\[(\d+):(\d+)\]', tok)
@@ -45,7 +53,7 @@ def scan(path):
                     print(f'{kern}:{ln}: MFMA reads v{sorted(h["dst"] & (a|b|c))} written by inline asm {dist} wait states earlier (line {h["ln"]})'); n_find += 1
                 dist += h['waits']
                 if dist > WINDOW: break
-            hist.append(dict(kind='mfma', dst=d, c=c, asm=False, ln=ln, waits=1))
+            hist.append(dict(kind='mfma', dst=d, c=c, asm=False, ln=ln, waits=1, need=need(op)))
         elif in_asm and op.startswith('v_'):
             d = regs(ops[0]); srcs = set()
             for o in ops[1:]: srcs |= regs(o)
@@ -54,7 +62,7 @@ def scan(path):
                 print(f'{kern}:{ln}: asm {op} reads v{sorted(hist[-1]["dst"] & srcs)} written by the transcendental instruction directly in front (line {hist[-1]["ln"]})'); n_find += 1
             dist = 0
             for h in reversed(hist):
-                if h['kind'] == 'mfma':
+                if h['kind'] == 'mfma' and dist < h['need']:
                     if h['dst'] & srcs: print(f'{kern}:{ln}: asm {op} RAW on MFMA vDst v{sorted(h["dst"] & srcs)} ({dist} wait states, mfma line {h["ln"]})'); n_find += 1
                     if h['dst'] & d: print(f'{kern}:{ln}: asm {op} WAW on MFMA vDst v{sorted(h["dst"] & d)} ({dist} wait states, mfma line {h["ln"]})'); n_find += 1
                     if h['c'] & d and h['c'] != h['dst']: print(f'{kern}:{ln}: asm {op} WAR on MFMA SrcC v{sorted(h["c"] & d)} ({dist} wait states, mfma line {h["ln"]})'); n_find += 1
