@@ -118,47 +118,44 @@ struct Stager {
   __device__ __forceinline__ float inv_scale() const { return inv_sc; }
 };
 
-// ---- RingStager (round 3, the C == 64 kernels): raw x reaches the workgroup by LDS-DMA, several chunks ahead.
-// Round 2 staged from registers one 32-channel chunk ahead: 8 KB in flight per workgroup, 16 KB per CU — by Little's law
-// ~2 TB/s for the whole chip at the ~2 us a loaded HBM round trip takes, which is what the two passes reached once the
-// benchmark stopped re-reading a cache-resident input (profiles/r03a_pmc_linattn.json: 1.3 / 1.85 TB/s algorithmic at
-// traffic_over_algorithmic 1.18 / 1.07; round 2's figures came from a 210 MB tensor that lived in the Infinity Cache).  A
-// chunk's matrix work is 0.3-0.5 us, so every second chunk waited for a whole round trip.  Here a unit = one chunk of one
-// sub-tile ([64 pixels][32 channels] fp32 = 8 KB; unit u = sub-tile u / 2, chunk u % 2) is fetched by
-// global_load_lds_dwordx4 — 8 pieces of 1 KB (8 pixels x 128 B), two per wave, no VGPRs, counted on vmcnt — into a ring of
-// RD units, RD - 1 units ahead (40 KB in flight per workgroup at RD = 6), with the sub-tile's 64 (mean, rstd) pairs
-// (global_load_lds_dword, 16 pixels per wave) in front of its first unit.  The staging pass reads the raw unit from LDS
-// (pixel pitch 128 B: the 16-lane service groups of ds_read_b128 fall on distinct banks), applies LayerNorm and the fp16
-// split exactly as Stager does, and writes the staged tile.  One raw s_barrier per chunk serves three purposes: the staged
-// tile is written, every wave's pieces of the NEXT unit have landed (each wave waits for its own with a counted vmcnt in
-// front of the barrier — a __syncthreads() would drain the DMA that must stay in flight), and the unit just read is free
-// for the DMA of unit u + RD.  No compiler-visible vector-memory load is left in the loop (hipcc would wait vmcnt(0) for
-// it and drain the ring): the LayerNorm gains sit in registers, the statistics come through the ring.
-// s_barrier without __syncthreads()'s fences (which would wait vmcnt(0) and drain the LDS-DMA that must stay in flight).
-// The intrinsic is declared as touching no memory, so hipcc may move LDS accesses across it: the empty asm statements pin
-// them (round 3: without the second one the fragment reads of the next unit were free to move above the barrier wherever no
-// DMA issue followed it — the last RD units of every workgroup — and the kernel computed from half-written tiles whenever a
-// neighbouring kernel skewed the waves: tests/test_gpu_soak.py, 58 of 60 launches).
+// ---- RingStager (round 3, pass 1 at C == 64): raw x reaches the workgroup by LDS-DMA, a whole sub-tile ahead, and a
+// sub-tile is staged in ONE pass.
+// Round 2 staged from registers one 32-channel chunk ahead and one chunk at a time: per sub-tile two latency chains (load ->
+// LayerNorm -> split -> LDS write; ~750 cycles each for ~40 instructions: tools/kv_stamps.py) and two barriers, 8 KB in flight
+// per workgroup.  Here a unit = one sub-tile ([64 pixels][64 channels] fp32 = 16 KB, contiguous in NHWC) is fetched by
+// global_load_lds_dwordx4 — 16 pieces of 1 KB, four per wave, no VGPRs, counted on vmcnt — into a ring of two units, with the
+// sub-tile's 64 (mean, rstd) pairs (global_load_lds_dword, 16 pixels per wave) in front of it.  The staging pass reads its
+// four 16 B runs per thread from the raw unit, applies LayerNorm and the fp16 split exactly as Stager does, and writes BOTH
+// chunks' staged tiles — into one of two tile SETS, so that one raw s_barrier per sub-tile is enough: it says the staged set
+// is written, every wave's pieces of the NEXT unit have landed (each wave waits vmcnt(0) in front of it: the next unit is all
+// it has outstanding; a __syncthreads() is avoided only because its fence would also be emitted where nothing needs it),
+// and the unit just read is free for the DMA of unit t + 2.  No compiler-visible vector-memory load is left in the loop
+// (hipcc would wait vmcnt(0) for it wherever its result is used): the LayerNorm gains sit in registers, the statistics come
+// through the ring, the kernel consumes every other load result in front of the loop.
+// What it bought (profiles/r03_linattn_notes.txt): deep prefetch alone (six chunk-units in flight, the first form) 162 -> 155
+// us — the pass was not waiting for HBM; see the notes for what it is waiting for.
+// s_barrier without __syncthreads()'s fences (which would also wait vmcnt(0) wherever they are emitted).  The intrinsic is
+// declared as touching no memory, so hipcc may move LDS accesses across it: the empty asm statements pin them (round 3:
+// without the second one the fragment reads behind the barrier were free to move above it wherever no asm statement — a DMA
+// issue — followed: tests/test_gpu_soak.py caught the kernel computing from half-written tiles, 58 of 60 launches).
 __device__ __forceinline__ void dmh_raw_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
 
-template <int RD>
 struct RingStager {
-  static constexpr int UNIT = TP * KC * 4;            // 8192
-  static constexpr int STATS_TILES = RD / 2 + 1;      // sub-tiles whose statistics may be in the ring at once
-  static constexpr int BYTES = RD * UNIT + STATS_TILES * TP * 8;
+  static constexpr int RD = 2;
+  static constexpr int UNIT = TP * 64 * 4;            // 16384: one sub-tile of 64 channels
+  static constexpr int STATS_SLOTS = 4;               // sub-tiles whose statistics may be in the ring at once (3) rounded up
+  static constexpr int BYTES = RD * UNIT + STATS_SLOTS * TP * 8;
   const float* xb;
   const float* stats_b;
-  int n, p0w, U;               // pixels per sample, first pixel of the workgroup, units of the workgroup (even)
+  int n, p0w, U;               // pixels per sample, first pixel of the workgroup, sub-tiles of the workgroup
   int c4, pix0, lane, wave;
   unsigned char* ring;
   unsigned ring_lds;
   float4 gq[2];
-  float mean[2], rstd[2];
-  bool ok[2];
   float sc, inv_sc;
   int seq = 0;
 
@@ -169,15 +166,14 @@ struct RingStager {
     n = n_;
     p0w = p0w_;
     const int left = (n - p0w + TP - 1) / TP;
-    U = 2 * (left < tiles ? left : tiles);
+    U = left < tiles ? left : tiles;
     lane = threadIdx.x & 63;
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c4 = threadIdx.x & 7;
     pix0 = threadIdx.x >> 3;
     ring = ring_;
     ring_lds = (unsigned)(size_t)ring_;
-    float m = 0.f;
-    m = fmaxf(fabsf(g[lane]), 0.f);                   // C == 64: one gain per lane
+    float m = fabsf(g[lane]);                         // C == 64: one gain per lane
 #pragma unroll
     for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
     const float bound = m * 8.0f;                     // sqrt(64) * max |g|  (Stager::init_scale)
@@ -196,82 +192,69 @@ struct RingStager {
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
   }
-  // unit u (< U): [its sub-tile's statistics, when it is the sub-tile's first chunk,] then the wave's two pieces
-  __device__ __forceinline__ void issue_unit(int u) {
-    const int tile = u >> 1, ch = u & 1;
-    const int p0 = p0w + tile * TP;
-    if (ch == 0) {   // statistics of the sub-tile: wave w brings the (mean, rstd) of its pixels 16 w .. 16 w + 15 (128 B)
-      const int fl = min((p0 + wave * 16) * 2 + (lane & 31), 2 * n - 1);      // clamped; pixels beyond n are masked later
-      if (lane < 32) glds(stats_b + fl, ring_lds + RD * UNIT + (tile % STATS_TILES) * (TP * 8) + wave * 128, false);
-    }
+  // sub-tile t (< U): its statistics, then the wave's four pieces (16 pixels x 256 B)
+  __device__ __forceinline__ void issue_unit(int t) {
+    const int p0 = p0w + t * TP;
+    const int fl = min((p0 + wave * 16) * 2 + (lane & 31), 2 * n - 1);        // clamped; pixels beyond n are masked later
+    if (lane < 32) glds(stats_b + fl, ring_lds + RD * UNIT + (t % STATS_SLOTS) * (TP * 8) + wave * 128, false);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int piece = wave * 2 + j;                 // pixels 8 * piece .. + 7 of the unit, 128 B each
-      const int pc = min(p0 + piece * 8 + (lane >> 3), n - 1);
-      glds(xb + (size_t)pc * 64 + ch * KC + (lane & 7) * 4, ring_lds + (u % RD) * UNIT + piece * 1024, true);
+    for (int j = 0; j < 4; ++j) {
+      const int piece = wave * 4 + j;                 // pixels 4 * piece .. + 3 of the sub-tile, 256 B each
+      const int pc = min(p0 + piece * 4 + (lane >> 4), n - 1);
+      glds(xb + (size_t)pc * 64 + (lane & 15) * 4, ring_lds + (t % RD) * UNIT + piece * 1024, true);
     }
-  }
-  // pieces this wave has issued AFTER those of unit v (v + 1 .. last issued), bounded below: a smaller count only waits longer
-  __device__ __forceinline__ void wait_unit(int v, int last_issued) {
-    const int k = min(last_issued, U - 1) - v;        // younger units
-    // 2 pieces per unit + 1 statistics piece per sub-tile start among them (at least k / 2)
-    if (k >= 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-    else if (k == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-    else if (k == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (k == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __device__ __forceinline__ void prime() {
-    static_assert(RD == 6, "wait_unit counts for a ring of six units");
-    for (int u = 0; u < RD && u < U; ++u) issue_unit(u);
-    wait_unit(0, RD - 1);
+    if (U > 0) issue_unit(0);
+    if (U > 1) {
+      issue_unit(1);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // unit 1's five pieces may stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     dmh_raw_barrier();
   }
-  // stage unit `seq` into one of the two LDS tiles; returns the tile
-  __device__ __forceinline__ unsigned char* stage(unsigned char* tiles, const int ch) {   // ch == seq & 1 (a constant at the call)
-    const int u = seq++;
-    unsigned char* tile = tiles + ch * TILE_BYTES;
-    const unsigned char* raw = ring + (u % RD) * UNIT;
-    if (ch == 0) {
-      const int p0 = p0w + (u >> 1) * TP;
-      const float* st = reinterpret_cast<const float*>(ring + RD * UNIT + ((u >> 1) % STATS_TILES) * (TP * 8));
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float2 mr = *reinterpret_cast<const float2*>(st + (pix0 + 32 * i) * 2);
-        mean[i] = mr.x;
-        rstd[i] = mr.y;
-        ok[i] = p0 + pix0 + 32 * i < n;
-      }
-    }
-    const float4 gv = ch ? gq[1] : gq[0];
+  // stage sub-tile `seq` into tile set seq & 1: chunk 0 at the returned address, chunk 1 TILE_BYTES behind it
+  __device__ __forceinline__ unsigned char* stage(unsigned char* tiles) {
+    const int t = seq++;
+    unsigned char* set = tiles + (t & 1) * (2 * TILE_BYTES);
+    const unsigned char* raw = ring + (t % RD) * UNIT;
+    const int p0 = p0w + t * TP;
+    const float* st = reinterpret_cast<const float*>(ring + RD * UNIT + (t % STATS_SLOTS) * (TP * 8));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      float4 x = *reinterpret_cast<const float4*>(raw + (pix0 + 32 * i) * 128 + c4 * 16);
-      if (ok[i]) {
-        x.x = (x.x - mean[i]) * rstd[i] * gv.x;  // exactly chan_layernorm_kernel's expression
-        x.y = (x.y - mean[i]) * rstd[i] * gv.y;
-        x.z = (x.z - mean[i]) * rstd[i] * gv.z;
-        x.w = (x.w - mean[i]) * rstd[i] * gv.w;
-      } else {
-        x = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float2 mr = *reinterpret_cast<const float2*>(st + (pix0 + 32 * i) * 2);
+      const bool ok = p0 + pix0 + 32 * i < n;
+#pragma unroll
+      for (int ch = 0; ch < 2; ++ch) {
+        float4 x = *reinterpret_cast<const float4*>(raw + (pix0 + 32 * i) * 256 + ch * 128 + c4 * 16);
+        const float4 gv = gq[ch];
+        if (ok) {
+          x.x = (x.x - mr.x) * mr.y * gv.x;  // exactly chan_layernorm_kernel's expression
+          x.y = (x.y - mr.x) * mr.y * gv.y;
+          x.z = (x.z - mr.x) * mr.y * gv.z;
+          x.w = (x.w - mr.x) * mr.y * gv.w;
+        } else {
+          x = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        uint2 h1, h2;
+        dmh_split2(x.x, x.y, sc, h1.x, h2.x);
+        dmh_split2(x.z, x.w, sc, h1.y, h2.y);
+        unsigned char* dst = set + ch * TILE_BYTES + (pix0 + 32 * i) * PITCH + c4 * 8;
+        *reinterpret_cast<uint2*>(dst) = h1;
+        *reinterpret_cast<uint2*>(dst + 64) = h2;
       }
-      uint2 h1, h2;
-      dmh_split2(x.x, x.y, sc, h1.x, h2.x);
-      dmh_split2(x.z, x.w, sc, h1.y, h2.y);
-      unsigned char* dst = tile + (pix0 + 32 * i) * PITCH + c4 * 8;
-      *reinterpret_cast<uint2*>(dst) = h1;
-      *reinterpret_cast<uint2*>(dst + 64) = h2;
     }
-    return tile;
+    return set;
   }
-  // after stage() of unit u: the staged tile is written (and the reads of raw unit u are back: the writes depend on them);
-  // wait for this wave's pieces of unit u + 1, ONE barrier, then refill the slot every wave has just finished reading.
+  // after stage() of sub-tile t: the staged set is written (and the reads of raw unit t are back: the writes depend on them);
+  // wait for this wave's pieces of unit t + 1 (all it has in flight), ONE barrier, refill the slot every wave has finished reading
   __device__ __forceinline__ void sync() {
-    const int u = seq - 1;
+    const int t = seq - 1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (u + 1 < U) wait_unit(u + 1, u - 1 + RD);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     dmh_raw_barrier();
-    if (u + RD < U) issue_unit(u + RD);
+    if (t + RD < U) issue_unit(t + RD);
   }
   __device__ __forceinline__ float inv_scale() const { return inv_sc; }
 };
@@ -519,15 +502,15 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
                                                             const float* __restrict__ oscale, float* __restrict__ partial,
                                                             int n, int C, int nsplit, int tiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* tiles_lds = smem;  // two staging tiles, then the raw ring
+  unsigned char* tiles_lds = smem;  // two sets of two staging tiles, then the raw ring
   constexpr int RES = 2;            // C == 64: both chunks' weight fragments stay in registers
 
   const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
 
-  RingStager<6> st;
-  st.init(x + (size_t)b * n * C, stats + (size_t)b * n * 2, g, n, sp * tiles * TP, tiles, smem + 2 * TILE_BYTES);
+  RingStager st;
+  st.init(x + (size_t)b * n * C, stats + (size_t)b * n * 2, g, n, sp * tiles * TP, tiles, smem + 4 * TILE_BYTES);
   const int nch = 2;
 
   const uint4* wb = wkv + (size_t)h * nch * (8 * 64) + lane;
@@ -562,6 +545,19 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
   asm volatile("" ::"v"(st.gq[0].x), "v"(st.gq[0].y), "v"(st.gq[0].z), "v"(st.gq[0].w), "v"(st.gq[1].x), "v"(st.gq[1].y),
                "v"(st.gq[1].z), "v"(st.gq[1].w), "v"(osc[0]), "v"(osc[1]), "v"(osc[2]), "v"(osc[3]));
   st.prime();
+#ifdef DMH_STAMPS
+  // diagnostic build only (make stamps; tools/kv_stamps.py): per-wave cycle totals of each phase, written over the partial
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t_prev, t_now;
+#define KSTAMP(i)                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0);                                             \
+  tk[i] += t_now - t_prev;                                                       \
+  t_prev = t_now;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_prev)::"memory");
+#else
+#define KSTAMP(i)
+#endif
   for (int tI = 0; tI < tiles; ++tI) {
     const int p0 = (sp * tiles + tI) * TP;
     if (p0 >= n) break;
@@ -571,10 +567,13 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = float4v{0.f, 0.f, 0.f, 0.f};
 
+    const unsigned char* set = st.stage(tiles_lds);
+    KSTAMP(0)  // staging: raw sub-tile -> LayerNorm -> fp16 pieces -> the two LDS tiles of a set
+    st.sync();
+    KSTAMP(1)  // waits, barrier, DMA issue
 #pragma unroll
     for (int ch = 0; ch < 2; ++ch) {
-      const unsigned char* tile = st.stage(tiles_lds, ch);
-      st.sync();
+      const unsigned char* tile = set + ch * TILE_BYTES;
       half8 a[4][2];
 #pragma unroll
       for (int mb = 0; mb < 4; ++mb)
@@ -589,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
       LA_TERM(0, __builtin_bit_cast(half8, wres[ch][nb * 2]))
 #undef LA_TERM
     }
+    KSTAMP(2)  // fragment reads + 96 projection MFMAs
     const float inv_s = st.inv_scale();
 
     // ---- k, v of this sub-tile: acc[mb][nb][r] = value(pixel p0 + mb*16 + 4*kg + r, column nb*16 + l15)
@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
     }
     // v: one power-of-two scale for the wave's 64 pixels x 32 columns (fp16 pieces are floating point: a block-wide
     // scale costs range, not precision — as in the conv kernels), so the product is unscaled by one uniform factor
+    KSTAMP(3)  // k: maxima, exponentials, sums, rescale of the running context, split of p
     // (round 3: 1 / block scale and the weight column's 2^-k — powers of two — ride on the split's multiplier, which is exact;
     //  the block maximum is taken over the raw accumulators, one multiply per column.  The split's inline asm reads MFMA
     //  results directly: its multiplier depends on the maximum over ALL of them, so every accumulator register has been read
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
         dmh_split8(vv, sv, v1[eb][ks], v2[eb][ks]);
       }
     }
+    KSTAMP(4)  // v: block maximum, split
     float4v t[2][2];  // [eb][db]: four independent chains, term by term; A = v (rows e), B = p (columns d)
 #pragma unroll
     for (int eb = 0; eb < 2; ++eb)
@@ -708,6 +710,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
     for (int eb = 0; eb < 2; ++eb)
 #pragma unroll
       for (int db = 0; db < 2; ++db) ctx[eb][db] += t[eb][db] * inv_v;
+    KSTAMP(5)  // 24 context MFMAs + accumulation
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no LDS-DMA may still be on its way when the workgroup ends)
@@ -726,7 +729,12 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
     for (int eb = 0; eb < 2; ++eb)
       st4(out + 64 + (db * 16 + l15) * 32 + eb * 16 + 4 * kg,
           make_float4(ctx[eb][db][0], ctx[eb][db][1], ctx[eb][db][2], ctx[eb][db][3]));
+#ifdef DMH_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) out[i] = (float)tk[i];
+#endif
 }
+#undef KSTAMP
 
 // ------------------------------------------------------------------------------------------ pass 2
 // grid = B * nblk; workgroup covers `tiles` sub-tiles; wave = head.
@@ -1215,7 +1223,7 @@ extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, con
       const char* e = getenv("DMH_LA_LDS_PAD");
       return e ? atoi(e) : 0;
     }();
-    const int LDS = 2 * TILE_BYTES + RingStager<6>::BYTES + lds_pad;
+    const int LDS = 4 * TILE_BYTES + RingStager::BYTES + lds_pad;
     static bool attr = false;
     if (!attr) {
       hipError_t e = hipFuncSetAttribute((const void*)linattn_kv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
