@@ -31,6 +31,11 @@ class DmhConv(C.Structure):
                [('in_bound', C.c_void_p), ('in_bound_n', C.c_int32)]
 
 
+class DmhPackJob(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('ws', C.c_void_p), ('wpack', C.c_void_p), ('Cout', C.c_int32), ('C0', C.c_int32),
+                ('C1', C.c_int32), ('KH', C.c_int32), ('transposed', C.c_int32)]
+
+
 class DmhStep(C.Structure):
     _fields_ = [('objective', C.c_int32), ('clip', C.c_int32), ('mode', C.c_int32), ('cond_scale', C.c_float),
                 ('sqrt_recip_ac', C.c_float), ('sqrt_recipm1_ac', C.c_float), ('sqrt_ac', C.c_float),
@@ -44,6 +49,7 @@ SIGNATURES = {
     'dmh_ws_standardize': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
     'dmh_conv_pack_floats': (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     'dmh_pack_conv_weight': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_pack_conv_weights_multi': (c_int, [C.c_void_p, c_int, c_float, C.c_void_p]),
     'dmh_conv_up2_pack_floats': (c_i64, [c_int, c_int]),
     'dmh_pack_conv_weight_up2': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_conv_tiles': (c_int, [c_int, c_int, c_int, c_int]),

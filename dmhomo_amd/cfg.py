@@ -91,8 +91,9 @@ class Unet(nn.Module):
                                  mask.to(torch.float32).contiguous(), reps=1, cpad=eng.cin_pad)
         return eng.stem(xin)
 
-    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None, x0=None):
-        """rows [rep*B + b]: sample b under class-keep mask keeps[rep] -> (len(keeps)*B, out_dim, H, W)."""
+    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None, x0=None, first=None):
+        """rows [rep*B + b]: sample b under class-keep mask keeps[rep] -> (len(keeps)*B, out_dim, H, W).
+        first: engine.first_conv(x0) when the caller shares it between passes."""
         eng = self._engine
         if x0 is None:
             x0 = self._stem(x, rgb_flow, mask)
@@ -101,7 +102,7 @@ class Unet(nn.Module):
         time = time.to(torch.int64).contiguous()
         classes = classes.to(torch.int64).contiguous()
         cond = eng.embed(time, [(classes, k) for k in keeps], len(keeps))
-        return eng.trunk(x0, cond, taps)
+        return eng.trunk(x0, cond, taps, first=first)
 
     def forward(self, x, time, classes, rgb_flow, mask, cond_drop_prob=None):
         cond_drop_prob = default(cond_drop_prob, self.cond_drop_prob)
@@ -113,6 +114,9 @@ class Unet(nn.Module):
     # matrix-bound kernels.  Results are identical (rows are independent, tests pin that bitwise).
     cfg_mode = 'batched'
     stream_splits = 1      # 'streams' mode: row sub-batches per pass, each on its own stream
+    # 'streams' mode: downs.0.0.block1.proj(stem output) once for both passes (bitwise the same rows); DMH_SHARE_FIRST_CONV=0
+    # is the development knob for same-box A/Bs
+    share_first_conv = __import__('os').environ.get('DMH_SHARE_FIRST_CONV', '1') != '0'
 
     def _cond_null(self, x, time, classes, rgb_flow, mask):
         """the two passes of CFG:404,409: (cond logits, null logits)."""
@@ -126,6 +130,9 @@ class Unet(nn.Module):
                 self._side = tuple(torch.cuda.Stream(device=x.device) for _ in range(nstreams))
             cur = torch.cuda.current_stream()
             x0 = self._stem(x, rgb_flow, mask)                # once, on the main stream
+            # ... and with it the first convolution behind it: the class embedding reaches a ResnetBlock only through the
+            # scale / shift behind block1's GroupNorm, so downs.0.0.block1.proj(x0) is the same rows in both passes
+            first = self._engine.first_conv(x0) if self.share_first_conv else None
             cond_out = torch.empty((B, self.out_dim) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
             null_out = torch.empty_like(cond_out)
             bounds = [(i * B) // nsub for i in range(nsub + 1)]
@@ -137,7 +144,8 @@ class Unet(nn.Module):
                     st.wait_stream(cur)
                     with torch.cuda.stream(st):
                         kk = None if k is None else k[lo:hi].contiguous()
-                        o = self._run(None, time[lo:hi], classes[lo:hi], None, None, [kk], x0=x0[lo:hi])
+                        fs = None if first is None else (first[0][lo:hi], first[1][lo:hi])
+                        o = self._run(None, time[lo:hi], classes[lo:hi], None, None, [kk], x0=x0[lo:hi], first=fs)
                         dst[lo:hi].copy_(o)
             for st in self._side:
                 cur.wait_stream(st)
@@ -336,7 +344,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         clip = True                                          # ddim_sample's clip_denoised default, as sample() calls it
         # everything that is baked into the captured launches or into the step tables
         key = (tuple(shape), tuple(rgb_flow.shape), float(cond_scale), self.model.cfg_mode, int(self.model.stream_splits),
-               bool(self.model.dedup_dropped_rows), float(self.model.cond_drop_prob), eng._sig, self.sampling_timesteps,
+               bool(self.model.dedup_dropped_rows), bool(self.model.share_first_conv), float(self.model.cond_drop_prob), eng._sig, self.sampling_timesteps,
                self.num_timesteps, self.objective, float(self.ddim_sampling_eta), clip, self.__dict__['_host_cache'][0],
                str(device))
         st = self.__dict__.get('_graph_state')

@@ -391,6 +391,19 @@ extern "C" int dmh_pack_conv_weight_up2(const float* w, float* wpack, int Cout, 
   return dmh_f16x3_up2_pack(w, wpack, Cout, C0, (hipStream_t)stream);
 }
 
+extern "C" int dmh_pack_conv_weights_multi(const DmhPackJob* jobs, int njobs, float ws_eps, void* stream) {
+  DMH_REQUIRE(jobs && njobs > 0, "dmh_pack_conv_weights_multi: bad arguments");
+  DMH_REQUIRE(conv3_variant() == 9, "dmh_pack_conv_weights_multi: only the fp16-piece images (DMH_CONV3_VARIANT=9)");
+  for (int i = 0; i < njobs; ++i) {
+    const DmhPackJob& j = jobs[i];
+    DMH_REQUIRE(j.src && j.wpack && j.Cout > 0 && j.C0 > 0 && j.C1 >= 0 && (j.KH == 1 || j.KH == 3) &&
+                    (j.transposed == 0 || (j.transposed == 1 && j.C1 == 0)),
+                "dmh_pack_conv_weights_multi: job %d: stride-1 1x1 / 3x3 weights only (Cout %d, C0 %d, C1 %d, KH %d, transposed %d)",
+                i, j.Cout, j.C0, j.C1, j.KH, j.transposed);
+  }
+  return dmh_f16x3_pack_multi(jobs, njobs, ws_eps, (hipStream_t)stream);
+}
+
 extern "C" int dmh_ws_standardize(const float* w, float* w_out, int Cout, int K, float eps, void* stream) {
   DMH_REQUIRE(w && w_out && Cout > 0 && K > 0, "dmh_ws_standardize: bad arguments");
   hipLaunchKernelGGL(ws_standardize_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w, w_out, K, eps);

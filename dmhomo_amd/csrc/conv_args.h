@@ -70,6 +70,7 @@ int dmh_wino_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
 int64_t dmh_f16x3_pack_floats(int Cout, int C0, int C1, int KH, int KW);
 int dmh_f16x3_pack(const float* w, float* wpack, int Cout, int C0, int C1, int KH, int KW, hipStream_t st);
 int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st);
+int dmh_f16x3_pack_multi(const DmhPackJob* jobs, int njobs, float eps, hipStream_t st);
 int64_t dmh_f16x3_up2_pack_floats(int Cout, int C0);
 int dmh_f16x3_up2_pack(const float* w, float* wpack, int Cout, int C0, hipStream_t st);
 int dmh_f16x3_launch_up2(const DmhConv* d, int Hout, int Wout, hipStream_t st);

@@ -95,6 +95,11 @@ struct F16Cfg {
 
 __device__ __forceinline__ unsigned absbits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
 
+// floats of the fragment part of a plain (stride-1 1x1 / 3x3) image with T taps: f16x3_frag_floats for device code
+__device__ __forceinline__ int64_t f16x3_frag_floats_dev(int Cout, int C0, int C1, int T) {
+  return (int64_t)((Cout + 63) / 64) * ((C0 + KC - 1) / KC + (C1 + KC - 1) / KC) * T * 2 * STEP_U4 * 4;
+}
+
 }  // namespace
 
 template <int KH, int KW, int S, int UPS, int TH, int TW, int WM, int WN>
@@ -559,6 +564,161 @@ __global__ void pack_f16x3_weight_kernel(const float* __restrict__ w, const floa
   const _Float16 g1 = (_Float16)ws;
   const _Float16 g2 = (_Float16)(ws - (float)g1);
   wp[idx] = plane == 0 ? g1 : g2;
+}
+
+// ------------------------------------------------------------------------------ many weights at once (training re-pack)
+// dmh_pack_conv_weights_multi: the three phases of ws_standardize -> f16x3_wscale -> pack_f16x3_weight as table-driven
+// kernels over up to PM_MAX jobs per launch (the table travels as a kernel argument: HIP-graph capturable, no device table
+// to keep in step with the caller's buffers).  Plain stride-1 1x1 / 3x3 images only.
+static int64_t f16x3_frag_floats(int Cout, int C0, int C1, int KH, int KW);
+#define PM_MAX 32
+struct PmTable {
+  const float* src[PM_MAX];
+  float* ws[PM_MAX];
+  float* wpack[PM_MAX];
+  int Cout[PM_MAX], C0[PM_MAX], C1[PM_MAX], T[PM_MAX], tr[PM_MAX];
+  int blk0[PM_MAX + 1];
+  int count;
+};
+__device__ __forceinline__ int pm_find(const PmTable& t, int blk) {
+  int lo = 0, hi = t.count;  // blk0[lo] <= blk < blk0[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (t.blk0[mid] <= blk) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+// element (o, c, tap) of the weight an image is made from; transposed: the data-gradient conv's weight, read from the
+// forward weight [C][Cout][T] with the taps flipped
+__device__ __forceinline__ float pm_elem(const float* w, int o, int c, int tap, int Cout, int Cin, int T, int tr) {
+  return tr ? w[((size_t)c * Cout + o) * T + (T - 1 - tap)] : w[((size_t)o * Cin + c) * T + tap];
+}
+// phase 1: one block per (job, source output channel) — ws_standardize_kernel of conv.hip, same order of operations
+__global__ __launch_bounds__(256) void pm_ws_kernel(PmTable t, float eps) {
+  __shared__ float red[8];
+  const int ti = pm_find(t, blockIdx.x), o = blockIdx.x - t.blk0[ti];
+  const int K = (t.tr[ti] ? t.Cout[ti] : t.C0[ti] + t.C1[ti]) * t.T[ti];   // (a job's ws is in the SOURCE layout)
+  const float* wr = t.src[ti] + (size_t)o * K;
+  float* out = t.ws[ti] + (size_t)o * K;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) s += wr[i];
+  for (int off = 32; off; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)K;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const float d = wr[i] - mean;
+    q = fmaf(d, d, q);
+  }
+  for (int off = 32; off; off >>= 1) q += __shfl_xor(q, off);
+  if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = q;
+  __syncthreads();
+  const float var = (red[4] + red[5] + red[6] + red[7]) / (float)K;
+  const float rstd = 1.0f / sqrtf(var + eps);
+  for (int i = threadIdx.x; i < K; i += 256) out[i] = (wr[i] - mean) * rstd;
+}
+// phase 2: one 64-thread block per (job, padded output channel) — f16x3_wscale_kernel
+__global__ __launch_bounds__(64) void pm_wscale_kernel(PmTable t) {
+  const int ti = pm_find(t, blockIdx.x), o = blockIdx.x - t.blk0[ti];
+  const int Cout = t.Cout[ti], Cin = t.C0[ti] + t.C1[ti], T = t.T[ti], tr = t.tr[ti], K = Cin * T;
+  const float* w = t.ws[ti] ? t.ws[ti] : t.src[ti];
+  float* oscale = t.wpack[ti] + f16x3_frag_floats_dev(Cout, t.C0[ti], t.C1[ti], T);
+  float m = 0.f;
+  if (o < Cout)
+    for (int i = threadIdx.x; i < K; i += 64) m = fmaxf(m, fabsf(pm_elem(w, o, i / T, i % T, Cout, Cin, T, tr)));
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (threadIdx.x == 0) {
+    float sc = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      sc = ldexpf(1.f, min(max(e - 15, -100), 100));
+    }
+    oscale[o] = sc;
+  }
+}
+// phase 3: 256 fp16 elements of an image per block — pack_f16x3_weight_kernel (plain form)
+__global__ __launch_bounds__(256) void pm_pack_kernel(PmTable t) {
+  const int ti = pm_find(t, blockIdx.x);
+  const int Cout = t.Cout[ti], C0 = t.C0[ti], C1 = t.C1[ti], T = t.T[ti], tr = t.tr[ti];
+  const int nch0 = (C0 + KC - 1) / KC, nch1 = (C1 + KC - 1) / KC;
+  const int64_t frag = f16x3_frag_floats_dev(Cout, C0, C1, T);
+  const int64_t total = frag * 2;
+  const float* w = t.ws[ti] ? t.ws[ti] : t.src[ti];
+  const float* oscale = t.wpack[ti] + frag;
+  _Float16* wp = reinterpret_cast<_Float16*>(t.wpack[ti]);
+  // (a block covers PM_PACK_PER_BLOCK consecutive elements)
+  const int64_t base = (int64_t)(blockIdx.x - t.blk0[ti]) * 2048;
+  for (int64_t idx = base + threadIdx.x; idx < min(base + 2048, total); idx += 256) {
+    int64_t r = idx;
+    const int j = r % 8;
+    r /= 8;
+    const int lane = r % 64;
+    r /= 64;
+    const int plane = r % 2;
+    r /= 2;
+    const int nb = r % 2;
+    r /= 2;
+    const int nh = r % 2;
+    r /= 2;
+    const int tap = r % T;
+    r /= T;
+    const int ch = r % (nch0 + nch1);
+    const int nt = r / (nch0 + nch1);
+    const int o = nt * 64 + nh * 32 + nb * 16 + (lane & 15);
+    const int k = (lane >> 4) * 8 + j;
+    int c;
+    bool ok;
+    if (ch < nch0) {
+      c = ch * KC + k;
+      ok = c < C0;
+    } else {
+      c = (ch - nch0) * KC + k;
+      ok = c < C1;
+      c += C0;
+    }
+    float ws = 0.f;
+    if (ok && o < Cout) ws = pm_elem(w, o, c, tap, Cout, C0 + C1, T, tr) / oscale[o];  // exact: a power of two
+    const _Float16 g1 = (_Float16)ws;
+    const _Float16 g2 = (_Float16)(ws - (float)g1);
+    wp[idx] = plane == 0 ? g1 : g2;
+  }
+}
+
+int dmh_f16x3_pack_multi(const DmhPackJob* jobs, int njobs, float eps, hipStream_t st) {
+  for (int phase = 0; phase < 3; ++phase) {
+    for (int i0 = 0; i0 < njobs;) {
+      PmTable t;
+      int k = 0, blocks = 0;
+      for (; k < PM_MAX && i0 < njobs; ++i0) {
+        const DmhPackJob& j = jobs[i0];
+        if (phase == 0 && !j.ws) continue;
+        const int T = j.KH * j.KH;
+        t.src[k] = j.src;
+        t.ws[k] = j.ws;
+        t.wpack[k] = j.wpack;
+        t.Cout[k] = j.Cout;
+        t.C0[k] = j.C0;
+        t.C1[k] = j.C1;
+        t.T[k] = T;
+        t.tr[k] = j.transposed;
+        t.blk0[k] = blocks;
+        if (phase == 0) blocks += j.transposed ? j.C0 + j.C1 : j.Cout;                 // source output channels
+        else if (phase == 1) blocks += cdiv(j.Cout, 64) * 64;
+        else blocks += (int)cdiv64(f16x3_frag_floats(j.Cout, j.C0, j.C1, j.KH, j.KH) * 2, 2048);
+        ++k;
+      }
+      if (k == 0) continue;
+      t.blk0[k] = blocks;
+      t.count = k;
+      if (phase == 0) hipLaunchKernelGGL(pm_ws_kernel, dim3(blocks), dim3(256), 0, st, t, eps);
+      else if (phase == 1) hipLaunchKernelGGL(pm_wscale_kernel, dim3(blocks), dim3(64), 0, st, t);
+      else hipLaunchKernelGGL(pm_pack_kernel, dim3(blocks), dim3(256), 0, st, t);
+      DMH_CHECK_LAUNCH("dmh_pack_conv_weights_multi");
+    }
+  }
+  return DMH_OK;
 }
 
 // the 7x7 init conv with few input channels runs two taps per K slice (UPS == 4)

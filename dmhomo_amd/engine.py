@@ -183,12 +183,13 @@ class UnetEngine:
         self.mlp_b = torch.cat(mlp_b).contiguous()
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, r, x0, x1, ss_all, pixel_stats=False):
+    def _res(self, r, x0, x1, ss_all, pixel_stats=False, pre=None):
         """pixel_stats: return (x, stats) with the channel-LayerNorm statistics of x for the LinearAttention that
-        follows (None where the block's last kernel cannot produce them)."""
+        follows (None where the block's last kernel cannot produce them).  pre: (y1, st1) = block1's convolution of x0
+        and its GroupNorm partials, computed by the caller (``first_conv``)."""
         B, H, W, _ = x0.shape
         hw = H * W
-        y1, st1 = ops.conv2d(r.conv1, x0, x1, want_stats=True)
+        y1, st1 = pre if pre is not None else ops.conv2d(r.conv1, x0, x1, want_stats=True)
         ss = ss_all[:, r.ss_off:r.ss_off + 2 * r.cout]
         if ops.STATIC_BOUND:
             coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss, want_bound=True)
@@ -244,8 +245,17 @@ class UnetEngine:
         self.ensure_prepared()
         return ops.conv2d(self.init_conv, xin)
 
-    def trunk(self, x0, cond, taps=None):
+    def first_conv(self, x0):
+        """block1's convolution of downs.0.0 on the stem output (+ its GroupNorm partials).  The embedding enters a
+        ResnetBlock only behind that GroupNorm (scale / shift, CFG:206-210, 233-235), so this convolution — like the stem — is
+        the same for every classifier-free-guidance pass of a sample and is computed once per sample (CFG:404 and :409 each
+        run it; the rows are bitwise the same)."""
+        self.ensure_prepared()
+        return ops.conv2d(self.downs[0][0].conv1, x0, None, want_stats=True)
+
+    def trunk(self, x0, cond, taps=None, first=None):
         """everything after init_conv.  x0: stem() output with one row per row of ``cond``.
+        first: ``first_conv(x0)`` when the caller has it already (shared between the CFG passes).
         ``taps`` (dict) optionally receives the NHWC activation after each stage member, keyed like the
         reference's module names ('downs.0.0', 'mid_attn', ...): per-layer parity tests."""
         self.ensure_prepared()
@@ -259,7 +269,7 @@ class UnetEngine:
         r = x
         hs = []
         for i, (b1, b2, at, down) in enumerate(self.downs):
-            x = tap(f'downs.{i}.0', self._res(b1, x, None, ss_all))
+            x = tap(f'downs.{i}.0', self._res(b1, x, None, ss_all, pre=first if i == 0 else None))
             hs.append(x)
             x, pst = self._res(b2, x, None, ss_all, pixel_stats=True) if at.pla is not None else \
                 (self._res(b2, x, None, ss_all), None)

@@ -32,25 +32,73 @@ def ws_standardize(w, eps=1e-5):
     return out
 
 
-class PackedConv:
-    """a conv weight in dmh_conv2d's tile-major layout + its geometry."""
-    __slots__ = ('wpack', 'bias', 'cout', 'c0', 'c1', 'k', 'stride', 'upsample2')
+class PackBatch:
+    """the weights a training step re-packs after every optimiser update, as ONE table for dmh_pack_conv_weights_multi
+    (three kernel phases over all of them) + the few that need their own launches (``specials``: closures that pack into
+    buffers allocated once).  Buffers and source pointers are fixed when the batch is built; ``run()`` is graph-capturable."""
 
-    def __init__(self, w_oihw, bias, c0, c1=0, stride=1, upsample2=0, subpixel=True):
-        w = w_oihw.detach().contiguous()
+    def __init__(self):
+        self.jobs, self.pre, self.specials, self._keep, self._arr = [], [], [], [], None
+
+    def add(self, src, ws, wpack, cout, c0, c1, kh, transposed):
+        self.jobs.append(_lib.DmhPackJob(ptr(src), ptr(ws), ptr(wpack), cout, c0, c1, kh, int(transposed)))
+        self._keep.append((src, ws, wpack))
+        self._arr = None
+
+    def run(self, eps=1e-5):
+        for f in self.pre:                 # (weights that are first assembled from the parameters: padded, re-indexed)
+            f()
+        if self.jobs:
+            if self._arr is None:
+                self._arr = (_lib.DmhPackJob * len(self.jobs))(*self.jobs)
+            call('dmh_pack_conv_weights_multi', C.cast(self._arr, C.c_void_p), len(self.jobs), float(eps))
+        for f in self.specials:
+            f()
+
+
+def _batchable(kh, stride, upsample2):
+    # (dmh_pack_conv_weights_multi makes the fp16-piece images of the default kernels only)
+    return kh in (1, 3) and stride == 1 and not upsample2 and os.environ.get('DMH_CONV3_VARIANT', '9') == '9'
+
+
+class PackedConv:
+    """a conv weight in dmh_conv2d's tile-major layout + its geometry.
+    batch (PackBatch): the image is NOT made here but by ``batch.run()`` — from ``w_oihw`` (whose storage must stay where
+    it is), or, with ``ws_from`` (the raw weight), from its standardised form, which the batch writes into ``w_oihw``."""
+    __slots__ = ('wpack', 'bias', 'cout', 'c0', 'c1', 'k', 'stride', 'upsample2', '_w', '_up2')
+
+    def __init__(self, w_oihw, bias, c0, c1=0, stride=1, upsample2=0, subpixel=True, batch=None, ws_from=None):
+        w = w_oihw.detach()
+        assert w.is_contiguous()
         cout, cin, kh, kw = w.shape
         assert cin == c0 + c1 and kh == kw, (w.shape, c0, c1)
+        self._w = w
         n_up2 = lib().dmh_conv_up2_pack_floats(cout, c0) if (upsample2 and kh == 3 and c1 == 0 and subpixel and SUBPIXEL_UP) else -1
-        if n_up2 > 0:                     # Upsample + conv3x3 as four 2x2 sub-pixel convs (upsample2 = 2)
+        self._up2 = n_up2 > 0
+        if self._up2:                     # Upsample + conv3x3 as four 2x2 sub-pixel convs (upsample2 = 2)
             self.wpack = _empty((n_up2,), w)
-            call('dmh_pack_conv_weight_up2', ptr(w), ptr(self.wpack), cout, c0)
             upsample2 = 2
         else:
-            n = lib().dmh_conv_pack_floats(cout, c0, c1, kh, kw)
-            self.wpack = _empty((n,), w)
-            call('dmh_pack_conv_weight', ptr(w), ptr(self.wpack), cout, c0, c1, kh, kw)
+            self.wpack = _empty((lib().dmh_conv_pack_floats(cout, c0, c1, kh, kw),), w)
         self.bias = None if bias is None else bias.detach().contiguous()
         self.cout, self.c0, self.c1, self.k, self.stride, self.upsample2 = cout, c0, c1, kh, stride, upsample2
+        if batch is not None and _batchable(kh, stride, upsample2):
+            if ws_from is not None:
+                batch.add(ws_from.detach(), w, self.wpack, cout, c0, c1, kh, 0)
+            else:
+                batch.add(w, None, self.wpack, cout, c0, c1, kh, 0)
+        else:
+            assert ws_from is None
+            if batch is not None:
+                batch.specials.append(self.repack)
+            self.repack()
+
+    def repack(self):
+        """(re)make the image from the weight tensor's current values"""
+        if self._up2:
+            call('dmh_pack_conv_weight_up2', ptr(self._w), ptr(self.wpack), self.cout, self.c0)
+        else:
+            call('dmh_pack_conv_weight', ptr(self._w), ptr(self.wpack), self.cout, self.c0, self.c1, self.k, self.k)
 
 
 def conv_out_hw(pc, h, w):
@@ -422,9 +470,27 @@ def conv_wgrad(dy, src0, src1=None, k=3, in_coef=None, want_bias=True, ups=0):
     return (dw, db) if want_bias else dw
 
 
-def conv_dgrad_pack(w, c_in_total):
+class _DgradPacked(PackedConv):
+    """the data-gradient conv of a stride-1 conv with weight w, its image made by a PackBatch from w itself (taps flipped
+    and (Cout, Cin) exchanged by index arithmetic in the pack kernel: no flipped / transposed copy of the weight)"""
+    __slots__ = ()
+
+    def __init__(self, w, c_in_total, batch):
+        w = w.detach()
+        cout_src, cin_src, kh, kw = w.shape
+        assert cin_src == c_in_total and kh == kw and w.is_contiguous()
+        self._w, self._up2 = w, False
+        self.wpack = _empty((lib().dmh_conv_pack_floats(cin_src, cout_src, 0, kh, kw),), w)
+        self.bias = None
+        self.cout, self.c0, self.c1, self.k, self.stride, self.upsample2 = cin_src, cout_src, 0, kh, 1, 0
+        batch.add(w, None, self.wpack, cin_src, cout_src, 0, kh, 1)
+
+
+def conv_dgrad_pack(w, c_in_total, batch=None):
     """PackedConv that computes the DATA gradient of a stride-1 conv with weight w (Cout, Cin, k, k): the same conv
     kernel on dy with the taps flipped and (Cout, Cin) transposed (no bias)."""
+    if batch is not None and _batchable(w.shape[-1], 1, 0):
+        return _DgradPacked(w, c_in_total, batch)
     wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, k, k)
     assert wt.shape[0] == c_in_total
     return PackedConv(wt, None, w.shape[0])
@@ -583,18 +649,23 @@ def conv_up_backward(dy, x, w, dpack=None):
 _DOWN_K = {0: {-1: 3, 0: 1}, 1: {0: 2, 1: 0}}
 
 
-def conv_down_dgrad_pack(w):
+def conv_down_dgrad_pack(w, batch=None):
     """PackedConv of the 3x3 conv over dy that yields the data gradient of the 4x4/stride-2 conv in pixel-shuffle
     layout: out[m][l][(ry*2+rx)*C + c] = dx[2m+ry][2l+rx][c]."""
     cout, c = w.shape[0], w.shape[1]
     w3 = torch.zeros((4 * c, cout, 3, 3), device=w.device, dtype=torch.float32)
-    for ry in (0, 1):
-        for rx in (0, 1):
-            par = ry * 2 + rx
-            for a, ky in _DOWN_K[ry].items():
-                for b, kx in _DOWN_K[rx].items():
-                    w3[par * c:(par + 1) * c, :, a + 1, b + 1] = w[:, :, ky, kx].t()
-    return PackedConv(w3, None, cout)
+
+    def fill():                            # (the taps that no parity reaches stay zero)
+        for ry in (0, 1):
+            for rx in (0, 1):
+                par = ry * 2 + rx
+                for a, ky in _DOWN_K[ry].items():
+                    for b, kx in _DOWN_K[rx].items():
+                        w3[par * c:(par + 1) * c, :, a + 1, b + 1] = w[:, :, ky, kx].t()
+    fill()
+    if batch is not None:
+        batch.pre.append(fill)
+    return PackedConv(w3, None, cout, batch=batch)
 
 
 def conv_down_backward(dy, x, w, dpack=None):

@@ -26,24 +26,30 @@ class ResnetBlockTrain:
     """one ResnetBlock with raw (trainable) parameters as device tensors.  ``p`` keys: w1 b1 g1 be1 w2 b2 g2 be2 and,
     when the block changes width, rw rb (the 1x1 res_conv).  c1 > 0: the input is cat(x0, x1) (up path)."""
 
-    def __init__(self, p, c0, c1=0, groups=8):
+    def __init__(self, p, c0, c1=0, groups=8, batch=None):
         self.p, self.c0, self.c1, self.groups = p, c0, c1, groups
-        self.refresh()
+        self.build(batch)
 
-    def refresh(self):
-        """(re)pack after a parameter update: standardised weights, forward and data-gradient images."""
+    def build(self, batch=None):
+        """standardised weights, forward and data-gradient images.  With ``batch`` (ops.PackBatch) the buffers are only
+        allocated and registered here: ``batch.run()`` fills them, now and after every parameter update."""
         p = self.p
-        self.w1s, self.w2s = ops.ws_standardize(p['w1']), ops.ws_standardize(p['w2'])
         cout = p['w1'].shape[0]
         self.cout = cout
-        self.f1 = ops.PackedConv(self.w1s, p['b1'], self.c0, self.c1)
-        self.f2 = ops.PackedConv(self.w2s, p['b2'], cout)
-        self.d1 = ops.conv_dgrad_pack(self.w1s, self.c0 + self.c1)
-        self.d2 = ops.conv_dgrad_pack(self.w2s, cout)
+        if batch is not None:
+            self.w1s, self.w2s = torch.empty_like(p['w1']), torch.empty_like(p['w2'])
+            self.f1 = ops.PackedConv(self.w1s, p['b1'], self.c0, self.c1, batch=batch, ws_from=p['w1'])
+            self.f2 = ops.PackedConv(self.w2s, p['b2'], cout, batch=batch, ws_from=p['w2'])
+        else:
+            self.w1s, self.w2s = ops.ws_standardize(p['w1']), ops.ws_standardize(p['w2'])
+            self.f1 = ops.PackedConv(self.w1s, p['b1'], self.c0, self.c1)
+            self.f2 = ops.PackedConv(self.w2s, p['b2'], cout)
+        self.d1 = ops.conv_dgrad_pack(self.w1s, self.c0 + self.c1, batch=batch)
+        self.d2 = ops.conv_dgrad_pack(self.w2s, cout, batch=batch)
         self.fr = self.dr = None
         if 'rw' in p:
-            self.fr = ops.PackedConv(p['rw'], p['rb'], self.c0, self.c1)
-            self.dr = ops.conv_dgrad_pack(p['rw'], self.c0 + self.c1)
+            self.fr = ops.PackedConv(p['rw'], p['rb'], self.c0, self.c1, batch=batch)
+            self.dr = ops.conv_dgrad_pack(p['rw'], self.c0 + self.c1, batch=batch)
 
     def forward(self, x0, x1=None, ss=None):
         """x0 (B,H,W,c0) [, x1 (B,H,W,c1)], ss (B, 2*cout) = (scale, shift) of the mlp -> out (B,H,W,cout), saved"""
@@ -92,12 +98,12 @@ class _LinAttn:
     """Residual(PreNorm(LinearAttention)) (CFG:96-103, 246-269) or, with linear=False, Residual(PreNorm(Attention))
     (CFG:273-296), on a stored qkv tensor."""
 
-    def __init__(self, p, c, linear):
+    def __init__(self, p, c, linear, batch=None):
         self.p, self.c, self.linear = p, c, linear
-        self.fq = ops.PackedConv(p['qkv'], None, c)
-        self.dq = ops.conv_dgrad_pack(p['qkv'], c)
-        self.fo = ops.PackedConv(p['ow'], p['ob'], HEADS * DIM_HEAD)
-        self.do = ops.conv_dgrad_pack(p['ow'], HEADS * DIM_HEAD)
+        self.fq = ops.PackedConv(p['qkv'], None, c, batch=batch)
+        self.dq = ops.conv_dgrad_pack(p['qkv'], c, batch=batch)
+        self.fo = ops.PackedConv(p['ow'], p['ob'], HEADS * DIM_HEAD, batch=batch)
+        self.do = ops.conv_dgrad_pack(p['ow'], HEADS * DIM_HEAD, batch=batch)
 
     def forward(self, x):
         p = self.p
@@ -132,15 +138,15 @@ class _LinAttn:
 class _Conv:
     """plain biased conv of the trunk: kind 'same3' (3x3), 'down4' (4x4 / stride 2), 'up3' (nearest x2 + 3x3), 'init7'."""
 
-    def __init__(self, w, b, kind, c):
+    def __init__(self, w, b, kind, c, batch=None):
         self.w, self.b, self.kind, self.c = w, b, kind, c
         k = w.shape[-1]
-        self.f = ops.PackedConv(w, b, c, 0, 2 if kind == 'down4' else 1, 1 if kind == 'up3' else 0)
+        self.f = ops.PackedConv(w, b, c, 0, 2 if kind == 'down4' else 1, 1 if kind == 'up3' else 0, batch=batch)
         self.d = None
         if kind in ('same3', 'up3'):
-            self.d = ops.conv_dgrad_pack(w, c)
+            self.d = ops.conv_dgrad_pack(w, c, batch=batch)
         elif kind == 'down4':
-            self.d = ops.conv_down_dgrad_pack(w)
+            self.d = ops.conv_down_dgrad_pack(w, batch=batch)
         self.k = k
 
     def forward(self, x):
@@ -165,9 +171,20 @@ class UnetTrain:
         self.module, self.groups = module, groups
         self.refresh()
 
+    def repack(self):
+        """the weight images from the parameters' CURRENT values (same buffers, same parameter storage as at the last
+        ``refresh()``): three table-driven launches for the ~140 plain convolution weights + the few special ones; a
+        handful of small tensors derived from parameters by torch ops are re-derived.  Graph-capturable."""
+        self.pack.run()
+        sd = self.sd
+        self.mlp_w.copy_(torch.cat([sd[k + '.mlp.1.weight'] for k in self.mlp_names], 0))
+        self.mlp_b.copy_(torch.cat([sd[k + '.mlp.1.bias'] for k in self.mlp_names], 0))
+
     def refresh(self):
+        """build everything from the module's parameters (first use, or after their storage moved)"""
         sd = {k: v.detach().to(torch.float32).contiguous() for k, v in self.module.named_parameters()}
         self.sd = sd
+        self.pack = pb = ops.PackBatch()
         self.dim = sd['time_mlp.1.weight'].shape[1]
         half = self.dim // 2
         import math
@@ -178,8 +195,13 @@ class UnetTrain:
         self.cin = w0.shape[1]
         self.cin_pad = (self.cin + 3) // 4 * 4
         wp = torch.zeros((w0.shape[0], self.cin_pad, 7, 7), device=dev)
-        wp[:, :self.cin] = w0
-        self.init = _Conv(wp, sd['init_conv.bias'], 'init7', self.cin_pad)
+        cin = self.cin
+
+        def pad_init():
+            wp[:, :cin] = w0
+        pad_init()
+        pb.pre.append(pad_init)
+        self.init = _Conv(wp, sd['init_conv.bias'], 'init7', self.cin_pad, batch=pb)
         self.blocks, self.ss_off, self.ss_total = {}, {}, 0
 
         def res(prefix, c0, c1=0):
@@ -189,7 +211,7 @@ class UnetTrain:
                      g2=sd[prefix + '.block2.norm.weight'], be2=sd[prefix + '.block2.norm.bias'])
             if (prefix + '.res_conv.weight') in sd:
                 p['rw'], p['rb'] = sd[prefix + '.res_conv.weight'], sd[prefix + '.res_conv.bias']
-            blk = ResnetBlockTrain(p, c0, c1, self.groups)
+            blk = ResnetBlockTrain(p, c0, c1, self.groups, batch=pb)
             self.blocks[prefix] = blk
             self.ss_off[prefix] = self.ss_total
             self.ss_total += 2 * blk.cout
@@ -202,7 +224,7 @@ class UnetTrain:
                 p['og'] = sd[prefix + '.fn.fn.to_out.1.g'].reshape(-1).contiguous()
             else:
                 p['ow'], p['ob'] = sd[prefix + '.fn.fn.to_out.weight'], sd[prefix + '.fn.fn.to_out.bias']
-            a = _LinAttn(p, c, linear)
+            a = _LinAttn(p, c, linear, batch=pb)
             self.blocks[prefix] = a
             return a
 
@@ -219,7 +241,7 @@ class UnetTrain:
             attn(pfx + '.2', c, True)
             skip_c.append(c)
             w = sd[pfx + '.3.weight']
-            self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.bias'], 'down4' if w.shape[-1] == 4 else 'same3', c)
+            self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.bias'], 'down4' if w.shape[-1] == 4 else 'same3', c, batch=pb)
             c = w.shape[0]
         res('mid_block1', c)
         attn('mid_attn', c, False)
@@ -233,16 +255,18 @@ class UnetTrain:
             attn(pfx + '.2', c, True)
             if (pfx + '.3.1.weight') in sd:
                 w = sd[pfx + '.3.1.weight']
-                self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.1.bias'], 'up3', c)
+                self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.1.bias'], 'up3', c, batch=pb)
             else:
                 w = sd[pfx + '.3.weight']
-                self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.bias'], 'same3', c)
+                self.blocks[pfx + '.3'] = _Conv(w, sd[pfx + '.3.bias'], 'same3', c, batch=pb)
             c = w.shape[0]
         res('final_res_block', c, self.init_dim)
         self.mlp_names = [k for k in self.ss_off]          # creation order == offsets order
         self.mlp_w = torch.cat([sd[k + '.mlp.1.weight'] for k in self.mlp_names], 0).contiguous()      # (total, emb)
         self.mlp_b = torch.cat([sd[k + '.mlp.1.bias'] for k in self.mlp_names], 0).contiguous()
         self.final_w = sd['final_conv.weight'].reshape(sd['final_conv.weight'].shape[0], -1).contiguous()   # (6, 64)
+        assert self.final_w.data_ptr() == sd['final_conv.weight'].data_ptr()      # a view: follows the parameter
+        pb.run()                                                 # the first fill of every image registered above
 
     # ------------------------------------------------------------------ small dense layers
     @staticmethod
@@ -599,18 +623,24 @@ class TrainStep:
     def refresh(self):
         """re-pack the training kernels' weight images from the (updated / loaded) parameters"""
         if self._repack_graph is None:
+            self.ut.refresh()                              # (re)build: buffers, the pack table, a first fill
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 # thread_local: other threads of the process (e.g. the RCCL watchdog) may keep calling into HIP meanwhile
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    self.ut.refresh()
+                    self.ut.repack()
                 self._repack_graph = g
             except Exception as e:                         # capture not available: stay on plain launches
                 print(f'dmhomo_amd: HIP graph capture of the weight re-pack failed ({e}); using plain launches')
                 self._repack_graph = False
+            return
         if self._repack_graph is False:
-            self.ut.refresh()
+            if tuple(p.data_ptr() for p in self.params.values()) != getattr(self, '_built_ptrs', None):
+                self.ut.refresh()
+            else:
+                self.ut.repack()
+            self._built_ptrs = tuple(p.data_ptr() for p in self.params.values())
         else:
             self._repack_graph.replay()
 

@@ -59,6 +59,25 @@ int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW);
  * straddle the two concatenated sources; padding is zero. */
 int dmh_pack_conv_weight(const float* w_oihw, float* wpack, int Cout, int C0, int C1, int KH, int KW,
                          void* stream);
+/* Many weights at once (the training step re-packs ~140 convolution weights after every optimiser update, DDP:1857: one
+ * image for the forward conv and one for the data-gradient conv of each): three kernel phases over ALL jobs — weight
+ * standardisation (N1) where a job asks for it, the per-output-channel power-of-two scales, the fp16-piece images — instead of
+ * two or three launches per weight.  Only the fp16-piece images of stride-1 1x1 / 3x3 convolutions (the default kernels).
+ *   src          OIHW weight the image is made from (after standardisation when ws != NULL)
+ *   ws           NULL, or [Cout_src][K] scratch: src is standardised into it first (CFG:120-126) and the image is made from it;
+ *                a later job may name this buffer as its src (phase 1 completes before phase 2 starts)
+ *   transposed   0: the image of conv(src).  1: the image of the DATA-GRADIENT conv of conv(src) — taps flipped, (Cout, Cin)
+ *                exchanged — for which Cout / C0 below are Cin_src / Cout_src and src is [C0][Cout][KH][KH]
+ * jobs is a HOST array; nothing is read from it after the call returns. */
+typedef struct DmhPackJob {
+  const float* src;
+  float* ws;
+  float* wpack;       /* dmh_conv_pack_floats(Cout, C0, C1, KH, KH) floats */
+  int32_t Cout, C0, C1, KH;
+  int32_t transposed;
+} DmhPackJob;
+int dmh_pack_conv_weights_multi(const DmhPackJob* jobs, int njobs, float ws_eps, void* stream);
+
 /* Upsample(nearest x2) + conv3x3 (CFG:106-107) in its sub-pixel form: output pixel (2y+dy, 2x+dx) depends on a 2x2
  * low-resolution neighbourhood through sums of the 3x3 taps, so the conv runs as four 2x2 convs (16 instead of 36
  * multiply-adds per low-resolution pixel; tap sums are formed in fp32 at pack time).  dmh_conv_up2_pack_floats returns
