@@ -1219,11 +1219,7 @@ extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, con
     return e ? atoi(e) : 1;
   }();
   if (C == 2 * KC && use_ring) {
-    static const int lds_pad = [] {   // experiment knob: extra LDS per workgroup (> 10 KB: one workgroup per CU)
-      const char* e = getenv("DMH_LA_LDS_PAD");
-      return e ? atoi(e) : 0;
-    }();
-    const int LDS = 4 * TILE_BYTES + RingStager::BYTES + lds_pad;
+    constexpr int LDS = 4 * TILE_BYTES + RingStager::BYTES;
     static bool attr = false;
     if (!attr) {
       hipError_t e = hipFuncSetAttribute((const void*)linattn_kv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);

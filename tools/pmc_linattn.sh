@@ -13,8 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/time -o p -- $B > $O/
 python3 - $O <<'PY'
 import collections, csv, glob, json, sys
 O = sys.argv[1]
-KERNELS = {'pass 1 (kv)': 'linattn_kv_kernel<2>', 'pass 2 (qo + to_out + LN + residual)': 'linattn_qo_kernel<true>'}
-GRID = '409600'          # 128x128, B = 50: 1600 workgroups (the 64x64 C = 64 case of linattn_bench.py has another grid)
+KERNELS = {'pass 1 (kv)': 'linattn_kv_ring_kernel', 'pass 2 (qo + to_out + LN + residual)': 'linattn_qo_kernel<true>'}
+GRID = "409600"          # 128x128, B = 50: 1600 workgroups
 def counters(d, kern):
     f = glob.glob(O + '/' + d + '/**/*counter_collection.csv', recursive=True)[0]
     agg, n = collections.defaultdict(float), collections.Counter()

@@ -25,6 +25,14 @@ cp "$(stats $O/g256)" $O/bench_256_batched_kernel_stats.csv
 python3 $R/bench.py --workload train --steps 5 --warmup 2 > $O/train_bench.json 2> $O/train_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t -- python3 $R/tools/train_bench.py --steps 3 --warmup 1 > $O/train.log 2>&1
 cp "$(stats $O/train)" $O/train_kernel_stats.csv
+# 4. the fused LinearAttention passes in isolation on HBM-resident inputs: counters, phase stamps (needs `make stamps`)
 rm -rf $O/streams $O/batched $O/pmc_fetch $O/pmc_write $O/stress $O/g256 $O/train
+bash $R/tools/pmc_linattn.sh > $O/pmc_linattn.log 2>&1
+cp $R/gpurun_out/pmc_la/pmc_linattn.json $O/pmc_linattn.json
+if [ -f $R/dmhomo_amd/libdmhomo_hip_stamps.so ]; then
+  (cd $R && python3 tools/kv_stamps.py 50 && python3 tools/la_stamps.py) > $O/linattn_stamps.txt 2>&1
+fi
+# 5. power / clock sample under the headline bench
+(cd $R && bash tools/power_sample.sh) > $O/power_sample.log 2>&1; cp $R/gpurun_out/power_sample.txt $O/power_sample.txt
 grep -h '"metric"' $O/bench.json $O/bench_256.json $O/bench_stress.json $O/train_bench.json | cut -c1-220
 ls -la $O
