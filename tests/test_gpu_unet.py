@@ -345,6 +345,44 @@ def test_sample_bs25_s32_rows_match_bs2():
     assert torch.equal(outs[25][:2], outs[2])
 
 
+def test_sample_bs25_s32_high_rows_vs_oracle():
+    """configs[1] at its real batch (bs = 25, s_step = 32, 128x128, 'streams'): rows 13 and 24 of the 25 against the
+    ORACLE run on those two samples alone with the same draws (the draws of the 25-row run are recorded and the two rows'
+    slices replayed) — an oracle number for rows beyond the first two of the batch (round 2 checked rows 0-1 against the
+    oracle and the rest HIP against HIP)"""
+    from dmhomo_amd import cfg
+    from dmhomo_amd.distributed import SampleIndexedRng
+    m, sd = make_cfg(64)
+    m.cfg_mode = 'streams'
+    d = cfg.GaussianDiffusion(m, image_size=128, timesteps=1000, sampling_timesteps=32, objective='pred_x0').to(dev())
+    rf01, flow, mk, c = _fullsize_s32_inputs(25)
+    rows = [13, 24]
+
+    class Rec:
+        def __init__(self, inner):
+            self.inner, self.draws = inner, []
+
+        def randn(self, shape, device):
+            v = self.inner.randn(shape, device)
+            self.draws.append(v[rows].cpu())
+            return v
+
+        def uniform(self, n, device):
+            v = self.inner.uniform(n, device)
+            self.draws.append(v[rows].cpu())
+            return v
+    d.rng = rec = Rec(SampleIndexedRng(11, range(25), dev()))
+    img, _, _ = d.sample(g(c), g(rf01), g(flow), g(mk))
+    m.cfg_mode = 'batched'
+    assert len(rec.draws) == 1 + 32 + 31                      # initial noise, 32 class-dropout draws, 31 step noises
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref, _, _ = OD.cfg_sample(sd, OD.schedule_buffers(1000, 'cosine'), c[rows], rf01[rows], flow[rows], mk[rows],
+                                  image_size=128, channels=6, sampling_timesteps=32, objective='pred_x0',
+                                  rng=OD.ReplayRng(rec.draws))
+    close('sample bs=25 S=32 rows 13, 24 vs oracle', img[rows].cpu(), ref, rtol=0, atol=2e-4)
+
+
 @pytest.mark.parametrize('mode,S,size', [('batched', 6, 32), ('streams', 6, 32), ('streams', 250, 16), ('batched', 1, 16)])
 def test_sample_hip_graph_equals_eager(mode, S, size):
     """GaussianDiffusion.hip_graph: ONE denoise step of the sampling loop (the hot loop CFG:683-707)
