@@ -116,15 +116,22 @@ __device__ __forceinline__ float lanes_sum(float v) {
 }
 
 // ---- the two fp16 pieces of x * s:  h = fp16(x * s),  r = fp16(x * s - h)  (pairs packed into dwords, low half first).
-// Four v_fma_mix per pair: each multiplies, subtracts the fp16 piece and converts in ONE instruction and from the UNROUNDED
-// product, so h + r carries 22 bits of x * s whatever s is (hipcc's own sequence for the C expression — packed multiply,
-// convert, convert back, packed fma, convert — is six per pair, and for a multiplier that is not a power of two it has been
-// seen to form the two pieces from differently rounded products: linattn_fused.hip).
+// r is formed from the UNROUNDED product (one fma), so h + r carries 22 bits of x * s whatever s is (hipcc's own sequence
+// for the C expression has been seen to form the two pieces from differently rounded products: linattn_fused.hip).
+// Round 3: six instructions per pair that cost 21.6 SIMD cycles instead of four v_fma_mixlo/hi_f16 that cost 32.7 — on
+// gfx950 the fp16-writing mix instructions issue at a QUARTER of the fp32 rate (8.2 cycles per wave64 instruction, like a
+// transcendental), v_cvt_pk_f16_f32 and v_fma_mix_f32 at half rate, v_mul_f32 at full rate (tools/micro/valu_rate.hip,
+// profiles/r03_micro_valu_rate.txt).  For a power-of-two s (every block scale) the pieces are bit for bit the old ones
+// (tools/micro/split_equiv.hip); for an arbitrary s (the softmax normaliser of linattn_qo_kernel) h is now rounded
+// fp32 -> fp16 from the rounded product, and r — still taken from the exact product — absorbs the difference.
 __device__ __forceinline__ void dmh_split2(float x0, float x1, float s, unsigned& h, unsigned& r) {
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x0), "v"(s), "v"(h));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(x1), "v"(s), "v"(h));
+  float t0, t1, u0, u1;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(t0) : "v"(x0), "v"(s));
+  asm("v_mul_f32 %0, %1, %2" : "=v"(t1) : "v"(x1), "v"(s));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(t0), "v"(t1));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(u0) : "v"(x0), "v"(s), "v"(h));
+  asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(u1) : "v"(x1), "v"(s), "v"(h));
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(u0), "v"(u1));
 }
 typedef _Float16 dmh_half8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void dmh_split8(const float (&x)[8], float s, dmh_half8& h, dmh_half8& r) {

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, NCB == 4 ? 2 : 1) void conv_wgrad_kernel(WgArg
 // forms the three kx operands in registers (v_alignbit for the odd shift, plain re-indexing for the even one).
 // Scales: per workgroup, running maxima of |dY| and |X| over its items (as in conv_f16x3.hip): when a later item raises a
 // maximum the accumulators are multiplied by the (power-of-two) ratio, so the scale only shrinks and nothing overflows.
-//     d1 = fp16(d*sd)  d2 = fp16(d*sd - d1)      x1 = fp16(x*sx)  x2 = fp16(x*sx - x1)      (dmh_split2: four v_fma_mix per pair)
+//     d1 = fp16(d*sd)  d2 = fp16(d*sd - d1)      x1 = fp16(x*sx)  x2 = fp16(x*sx - x1)      (dmh_split2: six instructions per pair)
 //     d*x*sd*sx = d1*x1 + d2*x1 + d1*x2 + O(2^-22)
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));

@@ -362,9 +362,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       if ((i + 1) * 256 <= IN_PIX * NQ || ((tid + i * 256) >> QS) < IN_PIX) {
-        // h1 = fp16(x * sc), h2 = fp16(x * sc - h1) (exact; see the header: stored unscaled) as eight v_fma_mix — each
-        // multiplies, subtracts the fp16 piece and converts in one instruction; hipcc's own sequence for the same values
-        // (packed multiply, convert, convert back, packed fma, convert) is twelve
+        // h1 = fp16(x * sc), h2 = fp16(x * sc - h1) (exact; see the header: stored unscaled): dmh_split2, twelve
+        // instructions per float4 at 43 SIMD cycles (round 2: eight v_fma_mixlo/hi_f16 at 65 — quarter-rate instructions)
         const float si = ((msk >> i) & 1u) ? sc : 0.f;   // padding is exactly zero: it pads the ACTIVATED tensor
         uint2 h1, h2;
         dmh_split2(v[i].x, v[i].y, si, h1.x, h2.x);
