@@ -415,7 +415,7 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
   DMH_REQUIRE(d && d->struct_size == sizeof(DmhConv),
               "dmh_conv2d: DmhConv.struct_size is %llu, this library's DmhConv has %llu bytes (header / library mismatch)",
               d ? (unsigned long long)d->struct_size : 0ull, (unsigned long long)sizeof(DmhConv));
-  DMH_REQUIRE(d->src0 && d->wpack && d->out, "dmh_conv2d: null pointer");
+  DMH_REQUIRE(d->src0 && d->wpack, "dmh_conv2d: null pointer");
   DMH_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->C0 > 0 && d->Cout > 0, "dmh_conv2d: bad shape");
   DMH_REQUIRE(d->C0 % 4 == 0 && (!d->src1 || d->C1 % 4 == 0),
               "dmh_conv2d: input channels must be a multiple of 4 (got %d, %d)", d->C0, d->C1);
@@ -429,6 +429,15 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
   const int Wout = conv_out_dim(d->Win, d->KW, d->stride, d->upsample2);
   const int key = d->KH * 100 + d->stride * 10 + d->upsample2;
   DMH_REQUIRE(d->KH == d->KW, "dmh_conv2d: non-square kernel");
+  if (d->fin_w) {
+    DMH_REQUIRE(d->fin_out && d->fin_n > 0 && d->fin_n <= 8, "dmh_conv2d: fin_w needs fin_out and 1 <= fin_n <= 8 (got %d)",
+                d->fin_n);
+    DMH_REQUIRE(d->KH == 1 && d->stride == 1 && d->Cout <= 64 && use_f16x3(1, 1),
+                "dmh_conv2d: the fused final projection rides on the 1x1 fp16-piece kernel with Cout <= 64 (got %dx%d, Cout %d)",
+                d->KH, d->KW, d->Cout);
+  } else {
+    DMH_REQUIRE(d->out, "dmh_conv2d: null pointer");
+  }
   switch (key) {
     case 110:
       if (use_f16x3(1, 1)) return dmh_f16x3_launch(d, Hout, Wout, st);

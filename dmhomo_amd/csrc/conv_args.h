@@ -17,6 +17,10 @@ struct ConvArgs {
   const float* oscale;  // per-output-channel power-of-two factor undoing the weight scaling (conv_f16x3.hip), or null
   const float* in_bound;  // null or [B][in_bound_n]: upper bounds of the prologue's |a*x + b| per sample (DmhConv.in_bound)
   int in_bound_n;
+  int fin_n;             // DmhConv.fin_*: the pointwise projection of the finished pixel (0: none)
+  const float* fin_w;
+  const float* fin_b;
+  float* fin_out;
   int B, Hin, Win, C0, C1, Cout, Hout, Wout;
   int nch0, nch1, tilesX, tilesY;
   int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
@@ -38,6 +42,10 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
   a.oscale = nullptr;
   a.in_bound = d->in_coef ? d->in_bound : nullptr;
   a.in_bound_n = d->in_bound_n;
+  a.fin_n = d->fin_w ? d->fin_n : 0;
+  a.fin_w = d->fin_w;
+  a.fin_b = d->fin_b;
+  a.fin_out = d->fin_out;
   a.B = d->B;
   a.Hin = d->Hin;
   a.Win = d->Win;
@@ -109,11 +117,11 @@ struct EpilogueRows {
   // wl: this wave's 32 slab rows; row_base: tile-row index of slab row 0 (row -> pixel (row / TW, row % TW))
   // (mul, dy, dx): the tile's pixel (y, x) lands on output pixel (mul*y + dy, mul*x + dx) — (2, parity) for the sub-pixel
   // form of Upsample + conv3x3, whose tiles live on the low-resolution grid
-  template <int TW>
+  template <int TW, bool FIN = false>
   __device__ __forceinline__ void store_rows(const ConvArgs& p, const float* wl, int row_base, int oy0, int ox0,
                                              int mul = 1, int dy = 0, int dx = 0) {
     const int c4_ = c4;
-    store_rows_fn<TW>(p, [wl, c4_](int rr) { return ld4(wl + rr * EP + c4_ * 4); }, row_base, oy0, ox0, mul, dy, dx);
+    store_rows_fn<TW, 8, FIN>(p, [wl, c4_](int rr) { return ld4(wl + rr * EP + c4_ * 4); }, row_base, oy0, ox0, mul, dy, dx);
   }
 
   // same, the 32 rows x this lane's channel quad coming from fetch(rr) instead of a plain slab
@@ -145,7 +153,7 @@ struct EpilogueRows {
     pre = true;
   }
 
-  template <int TW, int NR = 8, typename Fetch>
+  template <int TW, int NR = 8, bool FIN = false, typename Fetch>
   __device__ __forceinline__ void store_rows_fn(const ConvArgs& p, Fetch fetch, int row_base, int oy0, int ox0,
                                                 int mul = 1, int dy = 0, int dx = 0) {
     if (!pre) prefetch_rows<TW, NR>(p, row_base, oy0, ox0, mul, dy, dx);
@@ -182,9 +190,34 @@ struct EpilogueRows {
         }
       }
     }
+    if constexpr (FIN) {
+      // DmhConv.fin_*: the 16 lanes of a pixel hold its (<= 64) channels as quads — exactly final_conv_kernel's layout, and
+      // its arithmetic: per lane an fma chain over the quad from 0, row16_sum, + bias (bitwise the separate launch)
+      if (p.fin_n > 0) {
+        const int hw = p.Hout * p.Wout;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          if (o < p.fin_n) {
+            const float4 wq = cok ? ld4(p.fin_w + (size_t)o * p.Cout + chn) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float bo = p.fin_b ? p.fin_b[o] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+              float acc = fmaf(val[i].x, wq.x, 0.f);
+              acc = fmaf(val[i].y, wq.y, acc);
+              acc = fmaf(val[i].z, wq.z, acc);
+              acc = fmaf(val[i].w, wq.w, acc);
+              const float t = row16_sum(acc);
+              const int row = row_base + i * 4 + rsub;
+              const int oy = (oy0 + row / TW) * mul + dy, ox = (ox0 + row % TW) * mul + dx;
+              if (c4 == o && oy < p.Hout && ox < p.Wout) p.fin_out[((size_t)b * p.fin_n + o) * hw + oy * p.Wout + ox] = t + bo;
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      if (okr[i]) st4(p.out + oo[i], val[i]);
+      if (okr[i] && (!FIN || p.out)) st4(p.out + oo[i], val[i]);
       const float k = okr[i] ? 1.f : 0.f;     // rows outside the image do not enter the statistics
       const float vx = val[i].x * k, vy = val[i].y * k, vz = val[i].z * k, vw = val[i].w * k;
       s1.x += vx;

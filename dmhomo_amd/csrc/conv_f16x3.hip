@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (UPS == 3) er.template store_rows<TW>(p, wl, hb * 32, oy0, ox0, 2, wm >> 1, wm & 1);
-      else er.template store_rows<TW>(p, wl, wm * 64 + hb * 32, oy0, ox0);
+      else er.template store_rows<TW, (KH == 1 && KW == 1 && WN == 1 && UPS == 0)>(p, wl, wm * 64 + hb * 32, oy0, ox0);
     }
 #ifdef DMH_STAMPS
     STAMP(5)  // epilogue

@@ -24,6 +24,8 @@ from . import ops
 
 HEADS, DIM_HEAD = 4, 32     # CFG:246,275
 ATTN_SCALE = DIM_HEAD ** -0.5
+# development knob: '0' = final_conv as its own launch over the stored output of the last ResnetBlock
+FUSED_FINAL = os.environ.get('DMH_FUSED_FINAL', '1') != '0'
 FUSED_LINATTN = os.environ.get('DMH_FUSED_LINATTN', '1') != '0'   # development knob: '0' = separate LayerNorm / to_qkv / core
 
 
@@ -183,10 +185,11 @@ class UnetEngine:
         self.mlp_b = torch.cat(mlp_b).contiguous()
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, r, x0, x1, ss_all, pixel_stats=False, pre=None):
+    def _res(self, r, x0, x1, ss_all, pixel_stats=False, pre=None, final=None, keep_out=True):
         """pixel_stats: return (x, stats) with the channel-LayerNorm statistics of x for the LinearAttention that
         follows (None where the block's last kernel cannot produce them).  pre: (y1, st1) = block1's convolution of x0
-        and its GroupNorm partials, computed by the caller (``first_conv``)."""
+        and its GroupNorm partials, computed by the caller (``first_conv``).  final = (w, b): the block ends in its res_conv
+        launch, which also applies the UNet's final 1x1 projection to every finished pixel -> (x or None, y NCHW)."""
         B, H, W, _ = x0.shape
         hw = H * W
         y1, st1 = pre if pre is not None else ops.conv2d(r.conv1, x0, x1, want_stats=True)
@@ -197,6 +200,8 @@ class UnetEngine:
             coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss), None
         y2, st2 = ops.conv2d(r.conv2, y1, in_coef=coef1, want_stats=True, in_bound=bound1)
         coef2 = ops.gn_finalize(st2, r.g2, r.b2, hw, self.groups)
+        if final is not None:
+            return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, final=final, keep_out=keep_out)
         if r.res is not None:
             x = ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2)
             return (x, None) if pixel_stats else x
@@ -287,5 +292,13 @@ class UnetEngine:
             tap(f'ups.{i}.1', x)
             x = tap(f'ups.{i}.2', self._attn(at, x, pst))
             x = tap(f'ups.{i}.3', ops.conv2d(up, x))
-        x = tap('final_res_block', self._res(self.final_res, x, r, ss_all))
+        fr = self.final_res
+        if FUSED_FINAL and fr.res is not None and fr.res.k == 1 and fr.cout <= 64 and self.final_w.shape[0] <= 8 \
+                and ops.f16x3_default():
+            # final_conv (CFG:341, 471-472) rides on the last block's res_conv launch: the block's output is projected
+            # while it is still in registers, and only stored when a parity test taps it
+            x, y = self._res(fr, x, r, ss_all, final=(self.final_w, self.final_b), keep_out=taps is not None)
+            tap('final_res_block', x)
+            return y
+        x = tap('final_res_block', self._res(fr, x, r, ss_all))
         return ops.final_conv_nchw(x, self.final_w, self.final_b)

@@ -56,6 +56,11 @@ class PackBatch:
             f()
 
 
+def f16x3_default():
+    """the fp16-piece kernels (DMH_CONV3_VARIANT unset or 9) serve the 1x1 / 3x3 convolutions"""
+    return os.environ.get('DMH_CONV3_VARIANT', '9') == '9'
+
+
 def _batchable(kh, stride, upsample2):
     # (dmh_pack_conv_weights_multi makes the fp16-piece images of the default kernels only)
     return kh in (1, 3) and stride == 1 and not upsample2 and os.environ.get('DMH_CONV3_VARIANT', '9') == '9'
@@ -115,24 +120,35 @@ def conv_out_hw(pc, h, w):
 CONV_LOG = None
 
 
-def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False, in_bound=None):
+def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False, in_bound=None, final=None,
+           keep_out=True):
     """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats).
-    in_bound (B, k), with in_coef: upper bounds of the prologue's |a*x+b| per sample (gn_finalize(want_bound=True))."""
+    in_bound (B, k), with in_coef: upper bounds of the prologue's |a*x+b| per sample (gn_finalize(want_bound=True)).
+    final = (w (n, Cout), b (n,) or None), 1x1 convs with Cout <= 64 only: also apply that pointwise projection to every
+    finished output pixel and return (out, y) with y (B, n, H, W) NCHW — ``final_conv_nchw(out, w, b)`` without the second
+    pass over ``out`` (DmhConv.fin_*); keep_out=False: ``out`` itself is not stored (returned as None)."""
     B, H, W, c0 = src0.shape
     assert c0 == pc.c0 and (pc.c1 == 0) == (src1 is None), (src0.shape, pc.c0, pc.c1)
     if src1 is not None:
         assert src1.shape == (B, H, W, pc.c1), (src1.shape, pc.c1)
     ho, wo = conv_out_hw(pc, H, W)
-    out = _empty((B, ho, wo, pc.cout), src0)
+    assert keep_out or final is not None
+    out = _empty((B, ho, wo, pc.cout), src0) if keep_out else None
+    fin_w = fin_b = fin_out = None
+    if final is not None:
+        fin_w, fin_b = final
+        assert fin_w.shape[1] == pc.cout and fin_w.is_contiguous() and not want_stats, (fin_w.shape, pc.cout)
+        fin_out = _empty((B, fin_w.shape[0], ho, wo), src0)
     stats = None
     if want_stats:
         tiles = lib().dmh_conv_tiles(ho, wo, pc.k, pc.stride)
         stats = _empty((B, tiles, pc.cout, 2), src0)
     if res is not None:
-        assert res.shape == out.shape, (res.shape, out.shape)
+        assert res.shape == (B, ho, wo, pc.cout), (res.shape, (B, ho, wo, pc.cout))
     d = _lib.DmhConv(C.sizeof(_lib.DmhConv), ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
                      ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2,
-                     ptr(in_bound), 0 if in_bound is None else in_bound.shape[1])
+                     ptr(in_bound), 0 if in_bound is None else in_bound.shape[1],
+                     0 if fin_w is None else fin_w.shape[0], ptr(fin_w), ptr(fin_b), ptr(fin_out))
     if CONV_LOG is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -141,6 +157,8 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
         CONV_LOG.append((e0, e1, pc.k, pc.stride, B, ho, wo, pc.c0 + pc.c1, pc.cout, pc.upsample2, in_coef is not None))
     else:
         call('dmh_conv2d', C.byref(d))
+    if final is not None:
+        return out, fin_out
     return (out, stats) if want_stats else out
 
 

@@ -36,7 +36,7 @@ extern "C" {
 const char* dmh_last_error(void);
 /* DMH_ABI_VERSION of the library: bumped whenever a struct layout or an entry point changes; a binding must refuse a
  * library whose version differs from the header it was written against (dmhomo_amd/_lib.py does). */
-#define DMH_ABI_VERSION 300
+#define DMH_ABI_VERSION 301
 int dmh_version(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -119,6 +119,14 @@ typedef struct DmhConv {
    * from max_i in_bound instead of searching the staged tile for its maximum; the result is the same convolution. */
   const float* in_bound;
   int32_t in_bound_n;
+  /* optional (1x1, stride 1, Cout <= 64, the fp16-piece kernels): a second, pointwise projection applied to the finished
+   * output pixel while it is still in registers — fin_out[b][o][y][x] = fin_b[o] + sum_c fin_w[o][c] * out[b][y][x][c],
+   * o < fin_n <= 8, written NCHW: the UNet's final_conv (CFG:341, 471-472) fused into the last ResnetBlock's res_conv
+   * launch, bit for bit what dmh_final_conv_nchw computes from `out`.  With fin_w set, out may be NULL (not stored). */
+  int32_t fin_n;
+  const float* fin_w; /* [fin_n][Cout] */
+  const float* fin_b; /* [fin_n] or NULL */
+  float* fin_out;     /* NCHW [B][fin_n][Hout][Wout] */
 } DmhConv;
 
 /* tiles per sample that dmh_conv2d will use for this geometry (size of the stats buffer) */

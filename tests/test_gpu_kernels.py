@@ -160,6 +160,27 @@ def test_conv2d_prologue_and_residual(ops):
           rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize('B,H,W,C0,C1,Co,n', [(2, 18, 21, 64, 64, 64, 6), (3, 128, 128, 64, 64, 64, 6), (1, 7, 5, 32, 0, 48, 3),
+                                              (2, 16, 16, 64, 0, 64, 8)])
+def test_conv1x1_fused_final_projection(ops, B, H, W, C0, C1, Co, n):
+    """DmhConv.fin_*: the UNet's final_conv applied inside the last res_conv launch (cat input, GroupNorm + SiLU residual) is
+    bit for bit final_conv_nchw of that launch's stored output — with the output stored, and without storing it"""
+    x0, x1 = rand((B, H, W, C0), 40).to(dev()), (rand((B, H, W, C1), 41).to(dev()) if C1 else None)
+    pc = ops.PackedConv(rand((Co, C0 + C1, 1, 1), 42, (C0 + C1) ** -0.5).to(dev()), rand((Co,), 43, 0.1).to(dev()), C0, C1)
+    res = rand((B, H, W, Co), 44).to(dev())
+    rcoef = torch.stack([1 + 0.2 * rand((B, Co), 45), 0.3 * rand((B, Co), 46)], 1).contiguous().to(dev())
+    fw, fb = rand((n, Co), 47, Co ** -0.5).to(dev()), rand((n,), 48, 0.2).to(dev())
+    out = ops.conv2d(pc, x0, x1, res=res, res_coef=rcoef)
+    want = ops.final_conv_nchw(out, fw, fb)
+    out2, y = ops.conv2d(pc, x0, x1, res=res, res_coef=rcoef, final=(fw, fb))
+    assert torch.equal(out2, out) and torch.equal(y, want)
+    none, y2 = ops.conv2d(pc, x0, x1, res=res, res_coef=rcoef, final=(fw, None), keep_out=False)
+    assert none is None and torch.equal(y2, ops.final_conv_nchw(out, fw, None))
+    with pytest.raises(Exception, match='final projection'):
+        ops.conv2d(ops.PackedConv(rand((64, 64, 3, 3), 49, 0.05).to(dev()), None, 64), x0[..., :64].contiguous() if C0 >= 64
+                   else rand((B, H, W, 64), 50).to(dev()), final=(rand((n, 64), 51).to(dev()), None))
+
+
 @pytest.mark.parametrize('name,C0,C1,Co,H,k', [('3x3 64->64 @128', 64, 0, 64, 128, 3), ('3x3 64+64->64 @128', 64, 64, 64, 128, 3),
                                                ('3x3 512->512 @16', 512, 0, 512, 16, 3), ('1x1 64+64->64 @128', 64, 64, 64, 128, 1)])
 def test_conv2d_rows_independent_under_load(ops, name, C0, C1, Co, H, k):

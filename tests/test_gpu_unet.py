@@ -174,6 +174,25 @@ def test_fullsize_rows_independent_and_cfg_modes_agree():
     assert torch.equal(outs['batched'], outs['streams'])
 
 
+@pytest.mark.parametrize('dim,size', [(64, 128), (8, 16), (16, 40)])
+def test_final_conv_fused_into_last_res_conv_is_bitwise(dim, size, monkeypatch):
+    """final_conv (CFG:341, 471-472) rides on the last ResnetBlock's res_conv launch (DmhConv.fin_*): the forward is bit for
+    bit the one with final_conv as its own launch, and a tapped run (which stores the block output) agrees with both"""
+    from dmhomo_amd import engine as E
+    m, sd = make_cfg(dim)
+    x, rf, mk = _cond_inputs(2, size, 510)
+    t, c = torch.tensor([900, 17]), torch.zeros(2, dtype=torch.long)
+    assert E.FUSED_FINAL
+    fused = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=0.).clone()
+    monkeypatch.setattr(E, 'FUSED_FINAL', False)
+    plain = m(g(x), g(t), g(c), g(rf), g(mk), cond_drop_prob=0.).clone()
+    assert torch.equal(fused, plain)
+    monkeypatch.setattr(E, 'FUSED_FINAL', True)
+    taps = {}
+    tapped = m._run(g(x), g(t), g(c), g(rf), g(mk), [None], taps=taps)
+    assert torch.equal(tapped, fused) and taps['final_res_block'] is not None
+
+
 def test_unet_weight_update_is_picked_up():
     m, sd = make_cfg(8)
     x, rf, mk = _cond_inputs(1, 16, 300)
