@@ -20,7 +20,7 @@ c_int = C.c_int
 c_float = C.c_float
 
 
-ABI_VERSION = 301          # include/dmhomo_hip.h: DMH_ABI_VERSION
+ABI_VERSION = 302          # include/dmhomo_hip.h: DMH_ABI_VERSION
 
 
 class DmhConv(C.Structure):
@@ -29,7 +29,7 @@ class DmhConv(C.Structure):
                                           'stats')] + \
                [(n, C.c_int32) for n in ('B', 'Hin', 'Win', 'C0', 'C1', 'Cout', 'KH', 'KW', 'stride', 'upsample2')] + \
                [('in_bound', C.c_void_p), ('in_bound_n', C.c_int32), ('fin_n', C.c_int32), ('fin_w', C.c_void_p),
-                ('fin_b', C.c_void_p), ('fin_out', C.c_void_p)]
+                ('fin_b', C.c_void_p), ('fin_out', C.c_void_p), ('pix_stats', C.c_void_p), ('pix_eps', C.c_float)]
 
 
 class DmhPackJob(C.Structure):

@@ -438,6 +438,9 @@ extern "C" int dmh_conv2d(const DmhConv* d, void* stream) {
   } else {
     DMH_REQUIRE(d->out, "dmh_conv2d: null pointer");
   }
+  DMH_REQUIRE(!d->pix_stats || (d->KH == 1 && d->stride == 1 && d->Cout == 64 && use_f16x3(1, 1)),
+              "dmh_conv2d: pix_stats rides on the 1x1 fp16-piece kernel with Cout == 64 (got %dx%d, Cout %d)", d->KH, d->KW,
+              d->Cout);
   switch (key) {
     case 110:
       if (use_f16x3(1, 1)) return dmh_f16x3_launch(d, Hout, Wout, st);

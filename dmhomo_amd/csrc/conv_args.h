@@ -21,6 +21,8 @@ struct ConvArgs {
   const float* fin_w;
   const float* fin_b;
   float* fin_out;
+  float* pix_stats;      // DmhConv.pix_stats / pix_eps (null: none)
+  float pix_eps;
   int B, Hin, Win, C0, C1, Cout, Hout, Wout;
   int nch0, nch1, tilesX, tilesY;
   int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
@@ -46,6 +48,8 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
   a.fin_w = d->fin_w;
   a.fin_b = d->fin_b;
   a.fin_out = d->fin_out;
+  a.pix_stats = d->pix_stats;
+  a.pix_eps = d->pix_eps;
   a.B = d->B;
   a.Hin = d->Hin;
   a.Win = d->Win;
@@ -211,6 +215,24 @@ struct EpilogueRows {
               const int oy = (oy0 + row / TW) * mul + dy, ox = (ox0 + row % TW) * mul + dx;
               if (c4 == o && oy < p.Hout && ox < p.Wout) p.fin_out[((size_t)b * p.fin_n + o) * hw + oy * p.Wout + ox] = t + bo;
             }
+          }
+        }
+      }
+      // DmhConv.pix_stats (Cout == 64: the 16 lanes of a pixel hold all of its channels): pixel_stats_kernel<16, 1>'s two
+      // passes on the registers — sum, mean, centred second moment, in its order of operations
+      if (p.pix_stats) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          float s = (val[i].x + val[i].y) + (val[i].z + val[i].w);
+          s = lanes_sum<16>(s);
+          const float mean = s / 64.0f;
+          const float dx_ = val[i].x - mean, dy_ = val[i].y - mean, dz_ = val[i].z - mean, dw_ = val[i].w - mean;
+          float qsum = (dx_ * dx_ + dy_ * dy_) + (dz_ * dz_ + dw_ * dw_);
+          qsum = lanes_sum<16>(qsum);
+          if (c4 == 0 && okr[i]) {
+            float* ps = p.pix_stats + (oo[i] / (size_t)p.Cout) * 2;
+            ps[0] = mean;
+            ps[1] = 1.0f / sqrtf(qsum / 64.0f + p.pix_eps);
           }
         }
       }

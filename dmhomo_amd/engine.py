@@ -203,6 +203,10 @@ class UnetEngine:
         if final is not None:
             return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, final=final, keep_out=keep_out)
         if r.res is not None:
+            if pixel_stats and r.cout == 64 and r.res.k == 1 and 64 in ops.PIXEL_STATS_FUSABLE and ops.f16x3_default():
+                # (the up path at dim 64: the LayerNorm statistics of the LinearAttention behind this block come out of the
+                #  res_conv launch that finishes it — DmhConv.pix_stats — instead of a dmh_pixel_stats pass over its output)
+                return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, pixel_stats=True)
             x = ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2)
             return (x, None) if pixel_stats else x
         assert x1 is None

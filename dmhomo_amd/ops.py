@@ -121,12 +121,14 @@ CONV_LOG = None
 
 
 def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False, in_bound=None, final=None,
-           keep_out=True):
+           keep_out=True, pixel_stats=False, eps=1e-5):
     """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats).
     in_bound (B, k), with in_coef: upper bounds of the prologue's |a*x+b| per sample (gn_finalize(want_bound=True)).
     final = (w (n, Cout), b (n,) or None), 1x1 convs with Cout <= 64 only: also apply that pointwise projection to every
     finished output pixel and return (out, y) with y (B, n, H, W) NCHW — ``final_conv_nchw(out, w, b)`` without the second
-    pass over ``out`` (DmhConv.fin_*); keep_out=False: ``out`` itself is not stored (returned as None)."""
+    pass over ``out`` (DmhConv.fin_*); keep_out=False: ``out`` itself is not stored (returned as None).
+    pixel_stats (1x1 convs with Cout == 64): return (out, pstats) with pstats (B, H*W, 2) = the channel-LayerNorm (mean, rstd)
+    of every output pixel, as ``dmh_pixel_stats(out)`` gives them, for ``linear_attention_fused(..., stats=)``."""
     B, H, W, c0 = src0.shape
     assert c0 == pc.c0 and (pc.c1 == 0) == (src1 is None), (src0.shape, pc.c0, pc.c1)
     if src1 is not None:
@@ -139,6 +141,10 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
         fin_w, fin_b = final
         assert fin_w.shape[1] == pc.cout and fin_w.is_contiguous() and not want_stats, (fin_w.shape, pc.cout)
         fin_out = _empty((B, fin_w.shape[0], ho, wo), src0)
+    pst = None
+    if pixel_stats:
+        assert final is None and not want_stats and pc.cout == 64 and pc.k == 1, (pc.cout, pc.k)
+        pst = _empty((B, ho * wo, 2), src0)
     stats = None
     if want_stats:
         tiles = lib().dmh_conv_tiles(ho, wo, pc.k, pc.stride)
@@ -148,7 +154,7 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
     d = _lib.DmhConv(C.sizeof(_lib.DmhConv), ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
                      ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2,
                      ptr(in_bound), 0 if in_bound is None else in_bound.shape[1],
-                     0 if fin_w is None else fin_w.shape[0], ptr(fin_w), ptr(fin_b), ptr(fin_out))
+                     0 if fin_w is None else fin_w.shape[0], ptr(fin_w), ptr(fin_b), ptr(fin_out), ptr(pst), float(eps))
     if CONV_LOG is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -159,6 +165,8 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
         call('dmh_conv2d', C.byref(d))
     if final is not None:
         return out, fin_out
+    if pixel_stats:
+        return out, pst
     return (out, stats) if want_stats else out
 
 

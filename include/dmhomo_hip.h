@@ -36,7 +36,7 @@ extern "C" {
 const char* dmh_last_error(void);
 /* DMH_ABI_VERSION of the library: bumped whenever a struct layout or an entry point changes; a binding must refuse a
  * library whose version differs from the header it was written against (dmhomo_amd/_lib.py does). */
-#define DMH_ABI_VERSION 301
+#define DMH_ABI_VERSION 302
 int dmh_version(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -127,6 +127,11 @@ typedef struct DmhConv {
   const float* fin_w; /* [fin_n][Cout] */
   const float* fin_b; /* [fin_n] or NULL */
   float* fin_out;     /* NCHW [B][fin_n][Hout][Wout] */
+  /* optional (1x1, stride 1, Cout == 64, the fp16-piece kernels): pix_stats[(b*Hout + y)*Wout + x][2] = (mean, rstd) of the
+   * channel LayerNorm (CFG:137-141, eps pix_eps) of every finished output pixel — bit for bit what dmh_pixel_stats computes
+   * from `out` — for the fused LinearAttention that consumes this launch's output (the up path's res_conv, CFG:241 -> 246). */
+  float* pix_stats;
+  float pix_eps;
 } DmhConv;
 
 /* tiles per sample that dmh_conv2d will use for this geometry (size of the stats buffer) */

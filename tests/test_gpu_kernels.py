@@ -176,6 +176,11 @@ def test_conv1x1_fused_final_projection(ops, B, H, W, C0, C1, Co, n):
     assert torch.equal(out2, out) and torch.equal(y, want)
     none, y2 = ops.conv2d(pc, x0, x1, res=res, res_coef=rcoef, final=(fw, None), keep_out=False)
     assert none is None and torch.equal(y2, ops.final_conv_nchw(out, fw, None))
+    if Co == 64:   # DmhConv.pix_stats: the LayerNorm statistics of the output pixels, bitwise dmh_pixel_stats(out)
+        out3, pst = ops.conv2d(pc, x0, x1, res=res, res_coef=rcoef, pixel_stats=True)
+        want_st = torch.empty((B, H * W, 2), device=dev())
+        ops.call('dmh_pixel_stats', ops.ptr(out), ops.ptr(want_st), B * H * W, Co, 1e-5)
+        assert torch.equal(out3, out) and torch.equal(pst, want_st)
     with pytest.raises(Exception, match='final projection'):
         ops.conv2d(ops.PackedConv(rand((64, 64, 3, 3), 49, 0.05).to(dev()), None, 64), x0[..., :64].contiguous() if C0 >= 64
                    else rand((B, H, W, 64), 50).to(dev()), final=(rand((n, 64), 51).to(dev()), None))
