@@ -551,12 +551,12 @@ def gn_silu_backward(dout, y, coef, mr, gamma, beta, groups, ss=None):
         ss_ptr, ss_stride = C.c_void_p(ss.data_ptr()), ss.stride(0)
     call('dmh_gn_silu_backward', ptr(dout), ptr(y), ptr(coef), ptr(mr), ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(dy),
          ptr(pg), ptr(part), ptr(bcoef), B, hw, Cc, groups)
-    gb = _empty((2, Cc), y)
-    # pg is (B, 4, C): the first 2*C floats of each sample are its (dgamma, dbeta) parts
-    pgv = pg.reshape(B, 4 * Cc)
-    tmp = pgv[:, :2 * Cc].contiguous()
-    call('dmh_sum_over_batch', ptr(tmp), ptr(gb), B, 2 * Cc)
-    dss = pgv[:, 2 * Cc:].contiguous() if ss is not None else None
+    # pg is (B, 4, C): per sample (dgamma, dbeta, dscale, dshift) parts.  All four are summed over the batch in place (the
+    # last two sums are not used: cheaper than a strided copy of the first two in front of the kernel), and the (scale, shift)
+    # gradient goes back as a VIEW of pg — its one consumer copies it into its slice of the mlp output's gradient
+    gb = _empty((4, Cc), y)
+    call('dmh_sum_over_batch', ptr(pg), ptr(gb), B, 4 * Cc)
+    dss = pg.reshape(B, 4 * Cc)[:, 2 * Cc:] if ss is not None else None
     return dy, gb[0], gb[1], dss
 
 
