@@ -424,7 +424,8 @@ class UnetTrain:
                 else:
                     g[prefix + names[k]] = v.reshape(sd[prefix + names[k]].shape)
             if blk.c1:
-                return dx[..., :blk.c0].contiguous(), dx[..., blk.c0:].contiguous()
+                # (the skip half stays a channel-slice VIEW: its one consumer is the strided in-place add below)
+                return dx[..., :blk.c0].contiguous(), dx[..., blk.c0:]
             return dx, None
 
         def back_attn(d):
@@ -463,12 +464,12 @@ class UnetTrain:
         for i in reversed(range(self.ns)):
             ds1, ds2 = skip_grads[i]      # appended for ups.(ns-1), ..., ups.0; ups.j pops the pushes of downs.(ns-1-j)
             d = back_conv(d)                                     # downs.i.3
-            d = ops.add(d, ds1)                                  # downs.i.2's output was also pushed to the skip stack
+            d.add_(ds1)                                          # downs.i.2's output was also pushed to the skip stack
             d = back_attn(d)
             d, _ = back_res(d)                                   # downs.i.1
-            d = ops.add(d, ds2)                                  # downs.i.0's output was pushed too
+            d.add_(ds2)                                          # downs.i.0's output was pushed too
             d, _ = back_res(d)                                   # downs.i.0
-        d = ops.add(d, dr)                                       # r = init_conv output, also fed to final_res_block
+        d.add_(dr)                                               # r = init_conv output, also fed to final_res_block
         _, dw0, db0 = self.init.backward(sv['xin'], d, want_dx=False)
         g['init_conv.weight'], g['init_conv.bias'] = dw0[:, :self.cin].contiguous(), db0
         assert idx == 0
