@@ -1,3 +1,6 @@
+# A/B of a library build against dmhomo_amd/libdmhomo_prev.so (the previous build, same ABI version) on one box: kernel + soak tests,
+# every conv shape, the fused LinearAttention shapes, then the whole step three times alternating (used for the six-instruction fp16 split).
+#   gpurun -- bash tools/experiments/ab_split.sh
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_soak.py -m gpu -q -x 2>&1 | tail -2
 bash tools/ab_conv.sh dmhomo_amd/libdmhomo_prev.so --bound 2>&1 | grep -E "==|us" | cut -c1-60 | awk '/==/{tag=$2 $3} /us/{print tag, $0}' | sort -k2,2 -s

@@ -1,3 +1,5 @@
+"""dev tool: where one optimiser step of dmhomo_amd.train makes torch copy a tensor (non-contiguous .contiguous(), copy_, clone,
+zero_) — call site and shape, by count.   python tools/experiments/trace_copies.py"""
 import collections, os, sys, traceback
 sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/dmhomo_amd') else os.environ.get('GRAFT_REPO_ROOT','.'))
 import torch
