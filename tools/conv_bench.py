@@ -23,6 +23,10 @@ SHAPES = [  # name, B, H, W, C0, C1, Cout, k, stride, ups, prologue
     ('1x1_64+64_64_128_gnres', 50, 128, 128, 64, 64, 64, 1, 1, 0, 2),   # prologue field 2: + SiLU(a*res+b) residual epilogue
     ('1x1_128_512_16_res', 50, 16, 16, 128, 0, 512, 1, 1, 0, 3),        # 3: + plain residual (attention to_out)
     ('1x1_128_384_64', 50, 64, 64, 128, 0, 384, 1, 1, 0, 0),
+    ('1x1_128+64_128_64_gnres', 50, 64, 64, 128, 64, 128, 1, 1, 0, 2),   # the res_convs of the deeper up-path blocks
+    ('1x1_256+128_256_32_gnres', 50, 32, 32, 256, 128, 256, 1, 1, 0, 2),
+    ('1x1_512+256_512_16_gnres', 50, 16, 16, 512, 256, 512, 1, 1, 0, 2),
+    ('1x1_128_128_64_res', 50, 64, 64, 128, 0, 128, 1, 1, 0, 3),
     ('1x1_512_384_16', 50, 16, 16, 512, 0, 384, 1, 1, 0, 0),
     ('7x7_12_64_128', 50, 128, 128, 12, 0, 64, 7, 1, 0, 0),
     ('4x4s2_64_64_128', 50, 128, 128, 64, 0, 64, 4, 2, 0, 0),
