@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   // the order in which the steps are fetched and multiplied changes.
   constexpr bool ROWREUSE = KH == 3 && KW == 3 && S == 1 && UPS != 3 && UPS != 2;
   constexpr int NSTEP = NTAPS * 2;                  // steps per chunk
-  constexpr int NB = (NSTEP % 3 == 0) ? 3 : 2;      // NSTEP % NB == 0: a step's buffer index is static
+  // NSTEP % NB == 0: a step's buffer index is static.  Three buffers (weights two steps ahead) for the 8 x 16 x 128 layout; the
+  // 16 x 16 x 64 one has registers for two (round 3: with the accumulator-major MFMA order a third buffer spilled)
+  constexpr int NB = (NSTEP % 3 == 0 && WN != 1) ? 3 : 2;
   uint4 bq[NB][4];
   auto tap_of = [](int pos) constexpr { return ROWREUSE ? (pos % 3) * 3 + pos / 3 : pos; };   // pos-th tap multiplied
   auto load_b = [&](int buf, int ch_, int st_) {    // st_ may run past the chunk: the first steps of the next one
@@ -213,18 +215,26 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   constexpr int QS = Cfg::QS, NQ = Cfg::NQ;
   const int c4 = tid & (NQ - 1);
   float4 v[NLOAD];
-  int poff[NLOAD], wroff[NLOAD];
+  // PACKPW (the 16x16-pixel layout of the plain 3x3 conv, which has no register to spare): one word per load — the LDS slot in
+  // the low half, the source pixel RELATIVE to the tile's first (clamped) pixel in the high half (<= 17 * Win + 17 < 2^16: the
+  // launcher checks); the tile's own offset rides on the scalar base address
+  constexpr bool PACKPW = KH == 3 && KW == 3 && S == 1 && UPS == 0 && WN == 1;
+  int poff[NLOAD], wroff[PACKPW ? 1 : NLOAD];
+  const int y0c = min(max(iy0, 0), Hlim - 1), x0c = min(max(ix0, 0), Wlim - 1);
+  const int pbase = PACKPW ? (b * p.Hin + y0c) * p.Win + x0c : 0;
   unsigned inside = 0;
 #pragma unroll
   for (int i = 0; i < NLOAD; ++i) {
     const int pix = (tid + i * 256) >> QS;
     const int pixc = pix < IN_PIX ? pix : IN_PIX - 1;
-    wroff[i] = (pixc / IN_W) * ROWP + (pixc % IN_W) * PITCH + c4 * 8;  // staging slot in the LDS tile
+    const int wro = (pixc / IN_W) * ROWP + (pixc % IN_W) * PITCH + c4 * 8;  // staging slot in the LDS tile
+    if (!PACKPW) wroff[i] = wro;
     const int yy = iy0 + pixc / IN_W, xx = ix0 + pixc % IN_W;
     const bool ok = pix < IN_PIX && yy >= 0 && yy < Hlim && xx >= 0 && xx < Wlim;
     const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
     const int sy = UPS == 1 ? (yc >> 1) : yc, sx = UPS == 1 ? (xc >> 1) : xc;
     poff[i] = UPS == 2 ? ((yc << 16) | xc) : (b * p.Hin + sy) * p.Win + sx;  // UPS == 2: the coarse cell, resolved per parity
+    if (PACKPW) poff[i] = wro | (((yc - y0c) * p.Win + (xc - x0c)) << 16);
     inside |= (ok ? 1u : 0u) << i;
   }
   unsigned inside_ch = inside;  // validity mask of the chunk whose loads are in flight (UPS == 2: depends on the parity)
@@ -256,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       a = ld_src + ((size_t)(b * p.Hin + yc) * p.Win + xc) * ld_C + ld_c;
       inside_ch |= (ok ? 1u : 0u) << i;
     } else {
-      a = ld_src + (size_t)poff[i] * ld_C + ld_c;
+      if (PACKPW) a = ld_src + (size_t)pbase * ld_C + (int)(((unsigned)poff[i] >> 16) * (unsigned)ld_C + (unsigned)ld_c);
+      else a = ld_src + (size_t)poff[i] * ld_C + ld_c;
     }
 #ifdef DMH_STAMPS
     a = (p.ablate & 32) ? ld_src + ld_c : a;        // ablation: the tile loads hit one cached line (latency / HBM share)
@@ -368,7 +379,10 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
         uint2 h1, h2;
         dmh_split2(v[i].x, v[i].y, si, h1.x, h2.x);
         dmh_split2(v[i].z, v[i].w, si, h1.y, h2.y);
-        unsigned char* dst = in_tile + wroff[i];
+        int slot = PACKPW ? poff[i] : wroff[i];
+        // (volatile: hipcc otherwise hoists the eleven masks out of the chunk loop, into the registers the packing freed)
+        if (PACKPW) asm volatile("v_and_b32 %0, 0xffff, %0" : "+v"(slot));
+        unsigned char* dst = in_tile + slot;
         *reinterpret_cast<uint2*>(dst) = h1;
         *reinterpret_cast<uint2*>(dst + 64) = h2;
       }
@@ -431,17 +445,33 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
           else return a[mb][pl];
         };
 #define DMH_A(mb, pl) afrag(mb, pl)
-#define DMH_TERM(pl, bexpr)                                                                       \
-  _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 2; ++nb) \
-      acc[mb][(st & 1) * 2 + nb] =                                                                \
-          __builtin_amdgcn_mfma_f32_16x16x32_f16(bexpr, DMH_A(mb, pl), acc[mb][(st & 1) * 2 + nb], 0, 0, 0);
-        DMH_TERM(1, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h2 * g1   (smallest terms first)
-        DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2 + 1]))      // h1 * g2
-        DMH_TERM(0, __builtin_bit_cast(half8, bq[st % NB][nb * 2]))          // h1 * g1
-#undef DMH_TERM
+        // the three terms of ONE accumulator back to back, as one asm statement hipcc cannot pull apart: the matrix pipe
+        // forwards the accumulator between dependent MFMAs (full rate: tools/micro/issue_model.hip) instead of writing it to
+        // and reading it from the register file three times — fewer joules per product, and this kernel is power-limited
+        // (tools/micro/mfma_chain_power.hip: the same MFMAs on the same operands, 9-10 % faster in this order).  Per
+        // accumulator the order of the terms is unchanged: bitwise the same sums.
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            float4v& c = acc[mb][(st & 1) * 2 + nb];
+            const half8 g1 = __builtin_bit_cast(half8, bq[st % NB][nb * 2]), g2 = __builtin_bit_cast(half8, bq[st % NB][nb * 2 + 1]);
+            const half8 h1 = DMH_A(mb, 0), h2 = DMH_A(mb, 1);
+            asm("v_mfma_f32_16x16x32_f16 %0, %1, %4, %0\n\t"      // h2 * g1   (smallest terms first)
+                "v_mfma_f32_16x16x32_f16 %0, %2, %3, %0\n\t"      // h1 * g2
+                "v_mfma_f32_16x16x32_f16 %0, %1, %3, %0"           // h1 * g1
+                : "+v"(c) : "v"(g1), "v"(g2), "v"(h1), "v"(h2));
+          }
 #undef DMH_A
       }
     }
+    // hipcc does not know that the asm statements above are MFMAs: nothing of its own may read an accumulator before the last
+    // of them has written it (here: the rescale of the next chunk and the epilogue's slab writes, both a barrier away — the
+    // guard makes the distance a fact instead of a habit).  16 wait states, twice, pinned to every accumulator.
+#pragma unroll
+    for (int mb = 0; mb < 4; mb += 2)
+      asm volatile("s_nop 15" : "+v"(acc[mb][0]), "+v"(acc[mb][1]), "+v"(acc[mb][2]), "+v"(acc[mb][3]), "+v"(acc[mb + 1][0]),
+                   "+v"(acc[mb + 1][1]), "+v"(acc[mb + 1][2]), "+v"(acc[mb + 1][3]));
     __builtin_amdgcn_sched_barrier(0);
     STAMP(4)  // matrix phase
   }
@@ -850,6 +880,8 @@ int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
     return wide ? launch_f16x3<3, 3, 1, 1, 8, 16, 2, 2>(d, Hout, Wout, st)
                 : launch_f16x3<3, 3, 1, 1, 16, 16, 4, 1>(d, Hout, Wout, st);
   }
-  return wide ? launch_f16x3<3, 3, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st)
-              : launch_f16x3<3, 3, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);
+  if (wide) return launch_f16x3<3, 3, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st);
+  // (the 16 x 16 layout keeps a load's source pixel relative to the tile in 16 bits: PACKPW in the kernel)
+  DMH_REQUIRE(17 * (int64_t)d->Win + 17 < 65536, "dmh_conv2d: 3x3 with Cout %% 128 != 0 supports Win <= 3853 (got %d)", d->Win);
+  return launch_f16x3<3, 3, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);
 }

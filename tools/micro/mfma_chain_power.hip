@@ -1,0 +1,82 @@
+// micro-benchmark (round 3): does the order in which a wave's MFMAs visit its accumulators change what the chip can sustain
+// under its power cap?  Every SIMD of the chip runs two waves of v_mfma_f32_16x16x32_f16 on RANDOM fp16 operands (8 A and
+// 8 B fragments in registers, 8 accumulators), for milliseconds, in two orders:
+//   round-robin   acc0, acc1, ..., acc7, acc0, ...        (every accumulator read from / written to the register file)
+//   chained       acc0 x3, acc1 x3, ...                   (dependent MFMAs back to back: the pipe forwards the accumulator)
+// Same MFMA count, same operands.  Printed: wall time, in-kernel cycles, effective clock.
+//   hipcc --offload-arch=gfx950 -O2 tools/micro/mfma_chain_power.hip -o tools/micro/mfma_chain_power && tools/micro/mfma_chain_power
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int MODE>
+__global__ __launch_bounds__(512) void k(const half8* __restrict__ ops, float* out, unsigned long long* cyc, int iters) {
+  const int lane = threadIdx.x & 63;
+  half8 a[8], b[8];
+  for (int i = 0; i < 8; ++i) { a[i] = ops[(i * 64 + lane) * 2]; b[i] = ops[(i * 64 + lane) * 2 + 1]; }
+  float4v acc[8];
+  for (int i = 0; i < 8; ++i) acc[i] = float4v{0.f, 0.f, 0.f, 0.f};
+  unsigned long long t0, t1;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + r) & 7]), "v"(b[(i + 2 * r) & 7]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + r) & 7]), "v"(b[(i + 2 * r) & 7]));
+    }
+    if ((it & 63) == 63)   // keep the sums finite
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] *= 1e-3f;
+  }
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+int main() {
+  const int blocks = 256, iters = 20000;
+  half8* ops;
+  float* out;
+  unsigned long long* cyc;
+  (void)hipMalloc(&ops, 8 * 64 * 2 * sizeof(half8));
+  (void)hipMalloc(&out, blocks * 512 * 4);
+  (void)hipMalloc(&cyc, blocks * 8 * 8);
+  _Float16* h = (_Float16*)malloc(8 * 64 * 2 * 8 * 2);
+  srand(3);
+  for (int i = 0; i < 8 * 64 * 2 * 8; ++i) h[i] = (_Float16)((rand() / (float)RAND_MAX * 2.f - 1.f) * 100.f);
+  (void)hipMemcpy(ops, h, 8 * 64 * 2 * 8 * 2, hipMemcpyHostToDevice);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  static unsigned long long hc[256 * 8];
+  for (int rep = 0; rep < 3; ++rep)
+    for (int mode = 0; mode < 2; ++mode) {
+      (void)hipEventRecord(e0);
+      if (mode == 0) k<0><<<blocks, 512>>>(ops, out, cyc, iters);
+      else k<1><<<blocks, 512>>>(ops, out, cyc, iters);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      (void)hipMemcpy(hc, cyc, sizeof(hc), hipMemcpyDeviceToHost);
+      double c = 0;
+      for (int i = 0; i < blocks * 8; ++i) c += (double)hc[i];
+      c /= blocks * 8;
+      const double mf = (double)blocks * 8 * iters * 24;
+      printf("%-12s %8.3f ms  %10.0f cycles per wave (%.2f per MFMA and SIMD)  effective clock %.3f GHz  %.0f TFLOP/s\n",
+             mode ? "chained" : "round-robin", ms, c, c / (iters * 24.0) / 2.0, c / (ms * 1e6), mf * 16384 / (ms * 1e-3) / 1e12);
+    }
+  return 0;
+}
