@@ -11,6 +11,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+// MODE: 0 round-robin; 1 chains of 3; 2 chains of 6; 3 chains of 12; 4 one chain of 24 on a single accumulator per group;
+//       5 chains of 3 with the SAME A fragment inside a chain; 6 chains of 3 with the same A and the same B
 template <int MODE>
 __global__ __launch_bounds__(512) void k(const half8* __restrict__ ops, float* out, unsigned long long* cyc, int iters) {
   const int lane = threadIdx.x & 63;
@@ -27,12 +29,19 @@ __global__ __launch_bounds__(512) void k(const half8* __restrict__ ops, float* o
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + r) & 7]), "v"(b[(i + 2 * r) & 7]));
+    } else if (MODE <= 4) {
+      constexpr int L = MODE == 1 ? 3 : MODE == 2 ? 6 : MODE == 3 ? 12 : 24;
+#pragma unroll
+      for (int i = 0; i < 24 / L; ++i)
+#pragma unroll
+        for (int r = 0; r < L; ++r)
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + r) & 7]), "v"(b[(i + 2 * r) & 7]));
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int r = 0; r < 3; ++r)
-          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + r) & 7]), "v"(b[(i + 2 * r) & 7]));
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[MODE == 6 ? i : (i + 2 * r) & 7]));
     }
     if ((it & 63) == 63)   // keep the sums finite
 #pragma unroll
@@ -61,11 +70,19 @@ int main() {
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   static unsigned long long hc[256 * 8];
+  static const char* MN[7] = {"round-robin", "chains of 3", "chains of 6", "chains of 12", "chains of 24", "3, same A", "3, same A and B"};
   for (int rep = 0; rep < 3; ++rep)
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
       (void)hipEventRecord(e0);
-      if (mode == 0) k<0><<<blocks, 512>>>(ops, out, cyc, iters);
-      else k<1><<<blocks, 512>>>(ops, out, cyc, iters);
+      switch (mode) {
+        case 0: k<0><<<blocks, 512>>>(ops, out, cyc, iters); break;
+        case 1: k<1><<<blocks, 512>>>(ops, out, cyc, iters); break;
+        case 2: k<2><<<blocks, 512>>>(ops, out, cyc, iters); break;
+        case 3: k<3><<<blocks, 512>>>(ops, out, cyc, iters); break;
+        case 4: k<4><<<blocks, 512>>>(ops, out, cyc, iters); break;
+        case 5: k<5><<<blocks, 512>>>(ops, out, cyc, iters); break;
+        default: k<6><<<blocks, 512>>>(ops, out, cyc, iters); break;
+      }
       (void)hipEventRecord(e1);
       (void)hipEventSynchronize(e1);
       float ms;
@@ -75,8 +92,8 @@ int main() {
       for (int i = 0; i < blocks * 8; ++i) c += (double)hc[i];
       c /= blocks * 8;
       const double mf = (double)blocks * 8 * iters * 24;
-      printf("%-12s %8.3f ms  %10.0f cycles per wave (%.2f per MFMA and SIMD)  effective clock %.3f GHz  %.0f TFLOP/s\n",
-             mode ? "chained" : "round-robin", ms, c, c / (iters * 24.0) / 2.0, c / (ms * 1e6), mf * 16384 / (ms * 1e-3) / 1e12);
+      printf("%-16s %8.3f ms  %10.0f cycles per wave (%.2f per MFMA and SIMD)  effective clock %.3f GHz  %.0f TFLOP/s\n",
+             MN[mode], ms, c, c / (iters * 24.0) / 2.0, c / (ms * 1e6), mf * 16384 / (ms * 1e-3) / 1e12);
     }
   return 0;
 }
