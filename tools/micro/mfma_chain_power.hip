@@ -54,6 +54,45 @@ __global__ __launch_bounds__(512) void k(const half8* __restrict__ ops, float* o
   if (lane == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// the same FLOPs on v_mfma_f32_32x32x16_f16 (half the operand bytes, twice the accumulator bytes per multiply-add): 4 accumulators
+// of 16 registers, round-robin or chains of 3
+typedef float float16v __attribute__((ext_vector_type(16)));
+template <int MODE>
+__global__ __launch_bounds__(512) void k32(const half8* __restrict__ ops, float* out, unsigned long long* cyc, int iters) {
+  const int lane = threadIdx.x & 63;
+  half8 a[8], b[8];
+  for (int i = 0; i < 8; ++i) { a[i] = ops[(i * 64 + lane) * 2]; b[i] = ops[(i * 64 + lane) * 2 + 1]; }
+  float16v acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  unsigned long long t0, t1;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < iters; ++it) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + r) & 7]), "v"(b[(i + 2 * r) & 7]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a[(i + r) & 7]), "v"(b[(i + 2 * r) & 7]));
+    }
+    if ((it & 63) == 63)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] *= 1e-3f;
+  }
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 16; ++j) s += acc[i][j];
+  out[blockIdx.x * 512 + threadIdx.x] = s;
+  if (lane == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 int main() {
   const int blocks = 256, iters = 20000;
   half8* ops;
@@ -94,6 +133,18 @@ int main() {
       const double mf = (double)blocks * 8 * iters * 24;
       printf("%-16s %8.3f ms  %10.0f cycles per wave (%.2f per MFMA and SIMD)  effective clock %.3f GHz  %.0f TFLOP/s\n",
              MN[mode], ms, c, c / (iters * 24.0) / 2.0, c / (ms * 1e6), mf * 16384 / (ms * 1e-3) / 1e12);
+    }
+  for (int rep = 0; rep < 3; ++rep)
+    for (int mode = 0; mode < 2; ++mode) {
+      (void)hipEventRecord(e0);
+      if (mode == 0) k32<0><<<blocks, 512>>>(ops, out, cyc, iters);   // 12 MFMAs of twice the FLOPs per iteration: the same work
+      else k32<1><<<blocks, 512>>>(ops, out, cyc, iters);
+      (void)hipEventRecord(e1);
+      (void)hipEventSynchronize(e1);
+      float ms;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      const double mf = (double)blocks * 8 * iters * 12;
+      printf("32x32x16 %-16s %8.3f ms  %.0f TFLOP/s\n", mode ? "chains of 3" : "round-robin", ms, mf * 32768 / (ms * 1e-3) / 1e12);
     }
   return 0;
 }
