@@ -10,6 +10,10 @@ and for every MFMA: A/B/C sources written by an inline-asm VALU less than NOPS w
   TRANS a source written by a transcendental instruction (v_exp / v_log / v_rcp / v_rsq / v_sqrt / v_sin / v_cos) in the
         instruction directly in front (gfx940+ forwards a transcendental result one wait state late; hipcc pads its own
         consumers, not an inline-asm one).
+  ASM-MFMA (round 3: conv_f16x3.hip issues its MFMAs from inline asm, three per accumulator) for every vector / LDS / vector-memory
+        instruction OUTSIDE inline asm: any register it names that is the vDst of an inline-asm MFMA fewer than passes + 4 wait
+        states earlier — hipcc does not know those statements are MFMAs and pads nothing behind them (MFMA -> MFMA on the same
+        accumulator is interlocked by the hardware and not reported).
 Run by tests/test_isa_hazards.py over every source that contains inline-asm vector instructions.
 """
 import re, sys
@@ -53,7 +57,7 @@ def scan(path):
                     print(f'{kern}:{ln}: MFMA reads v{sorted(h["dst"] & (a|b|c))} written by inline asm {dist} wait states earlier (line {h["ln"]})'); n_find += 1
                 dist += h['waits']
                 if dist > WINDOW: break
-            hist.append(dict(kind='mfma', dst=d, c=c, asm=False, ln=ln, waits=1, need=need(op)))
+            hist.append(dict(kind='mfma', dst=d, c=c, asm=False, in_asm=in_asm, ln=ln, waits=1, need=need(op)))
         elif in_asm and op.startswith('v_'):
             d = regs(ops[0]); srcs = set()
             for o in ops[1:]: srcs |= regs(o)
@@ -70,6 +74,15 @@ def scan(path):
                 if dist > WINDOW: break
             hist.append(dict(kind='valu', dst=d, asm=True, ln=ln, waits=1))
         else:
+            if not in_asm and op.startswith(('v_', 'ds_', 'global_', 'buffer_', 'scratch_', 'flat_')):
+                named = set()
+                for o in ops: named |= regs(o)
+                dist = 0
+                for h in reversed(hist):
+                    if h['kind'] == 'mfma' and h.get('in_asm') and dist < h['need'] and h['dst'] & named:
+                        print(f'{kern}:{ln}: {op} names v{sorted(h["dst"] & named)}, the vDst of an inline-asm MFMA {dist} wait states earlier (line {h["ln"]})'); n_find += 1
+                    dist += h['waits']
+                    if dist > WINDOW: break
             d = regs(ops[0]) if ops and op.startswith(('v_', 'ds_read', 'global_load', 'buffer_load')) else set()
             trans = (not in_asm) and op.split('_e')[0] in ('v_exp_f32', 'v_log_f32', 'v_rcp_f32', 'v_rsq_f32', 'v_sqrt_f32', 'v_sin_f32', 'v_cos_f32')
             hist.append(dict(kind='other', dst=d, asm=False, ln=ln, waits=waits, trans=trans))
