@@ -203,7 +203,8 @@ class UnetEngine:
         if final is not None:
             return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, final=final, keep_out=keep_out)
         if r.res is not None:
-            if pixel_stats and r.cout == 64 and r.res.k == 1 and 64 in ops.PIXEL_STATS_FUSABLE and ops.f16x3_default():
+            if pixel_stats and r.cout == 64 and r.res.k == 1 and 64 in ops.PIXEL_STATS_FUSABLE and ops.f16x3_default() \
+                    and os.environ.get('DMH_CONV_PIXEL_STATS', '1') != '0':      # (knob: same-box A/Bs)
                 # (the up path at dim 64: the LayerNorm statistics of the LinearAttention behind this block come out of the
                 #  res_conv launch that finishes it — DmhConv.pix_stats — instead of a dmh_pixel_stats pass over its output)
                 return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, pixel_stats=True)
