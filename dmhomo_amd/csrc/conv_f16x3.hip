@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     const int yc = min(max(yy, 0), Hlim - 1), xc = min(max(xx, 0), Wlim - 1);
     const int sy = UPS == 1 ? (yc >> 1) : yc, sx = UPS == 1 ? (xc >> 1) : xc;
     poff[i] = UPS == 2 ? ((yc << 16) | xc) : (b * p.Hin + sy) * p.Win + sx;  // UPS == 2: the coarse cell, resolved per parity
-    if (PACKPW) poff[i] = wro | (((yc - y0c) * p.Win + (xc - x0c)) << 16);
+    if (PACKPW) poff[i] = (int)((unsigned)wro | ((unsigned)((yc - y0c) * p.Win + (xc - x0c)) << 16));
     inside |= (ok ? 1u : 0u) << i;
   }
   unsigned inside_ch = inside;  // validity mask of the chunk whose loads are in flight (UPS == 2: depends on the parity)

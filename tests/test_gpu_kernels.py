@@ -218,6 +218,13 @@ def test_conv2d_rejects_bad_channels(ops):
     pc = ops.PackedConv(rand((8, 6, 3, 3), 1).to(dev()), None, 6)
     with pytest.raises(DmhError):
         ops.conv2d(pc, torch.zeros((1, 4, 4, 6), device=dev()))
+    # the 16 x 16-pixel layout of the 3x3 kernel keeps a load's source pixel relative to its tile in 16 bits: wider images are
+    # refused with a message, not mis-addressed (the 8 x 16 x 128-channel layout has no such limit)
+    pc64 = ops.PackedConv(rand((64, 4, 3, 3), 2).to(dev()), None, 4)
+    with pytest.raises(DmhError, match='Win <= 3853'):
+        ops.conv2d(pc64, torch.zeros((1, 2, 4000, 4), device=dev()))
+    ok = ops.conv2d(pc64, torch.zeros((1, 2, 3853, 4), device=dev()))
+    assert ok.shape == (1, 2, 3853, 64) and float(ok.abs().max()) == 0.0
 
 
 def test_ws_standardize(ops):
