@@ -35,7 +35,13 @@
 //       through the fused prologue SiLU(a*x+b) when a GroupNorm is pending — as two fp16 planes and reused by
 //       all taps; the weight planes stream from L2 in fragment order, one coalesced 1 KB load per wave each,
 //       prefetched one K step ahead.
-// Epilogue: shared with conv.hip (LDS transpose, + bias, + residual, float4 NHWC stores, GroupNorm partials).
+//   MFMA order (round 3): the three terms of an accumulator are issued back to back as one asm statement — the matrix pipe
+//       forwards the accumulator between dependent MFMAs, so it crosses the register file once per three products; under the
+//       power cap that is worth +3.7 % images/s (tools/micro/mfma_chain_power.hip).  hipcc does not know those statements
+//       are MFMAs: a wait-state guard pinned to every accumulator closes each matrix phase (tools/hazard_scan.py checks the
+//       generated code for anything of hipcc's own that names such a register too soon).
+// Epilogue: shared with conv.hip (LDS transpose, + bias, + residual, float4 NHWC stores, GroupNorm partials; for the 1x1
+//       16x16 layout optionally the UNet's final projection and the LayerNorm statistics of the output: DmhConv.fin_*, pix_stats).
 //
 // UPS == 2 is the Downsample conv (4x4, stride 2, pad 1, CFG:110-111) as an exact 2x2 / stride-1 convolution over the
 // space-to-depth view of its input shifted by one pixel: X[cy][cx][(py, px, c)] = x[2cy-1+py][2cx-1+px][c], so
