@@ -13,8 +13,11 @@
 
 #define GNB_PCH 256  // pixels per partial chunk
 
+// SiLU'(z) = sg * (1 + z * (1 - sg)), sg = sigmoid(z) on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1-2 ulp) like
+// the forward's silu_fast (round 3: the exact expf + IEEE division made the reduce / apply kernels vector-bound — two reads of
+// the block's tensors at 3.7 TB/s)
 __device__ __forceinline__ float silu_grad(float z) {
-  const float sg = 1.0f / (1.0f + expf(-z));
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
   return sg * (1.0f + z * (1.0f - sg));
 }
 
