@@ -11,7 +11,8 @@ run as one 2B batch), bs=25 per GPU.  One "step" = one pass of the hot path over
 sample() (32 denoise steps) + the uint8 / homography record of Trainer.sample + (N>1) the
 gather to rank 0.  Inputs (conditions, weights) are resident in HBM before the timed region;
 weights are seeded random init (the trained DGM.pt is not available offline; speed is weight
-independent), noise comes from the device Philox generator.  Samples shard across ranks with no
+independent), noise comes from the sample-indexed device generator (dmh_rng_indexed: row i of an N-rank run is row i
+of the 1-GPU run).  Samples shard across ranks with no
 data-path collective -> "scaling": "weak" (25 samples per GPU).
 
 N > 1 without a torchrun environment: this process only LAUNCHES (it never touches the GPU): it starts
@@ -240,10 +241,11 @@ def main():
     # (ONE denoise step is captured and replayed s_step times: any depth, the 250-step stress configuration included)
     use_graph = not args.no_graph
     diffusion.hip_graph = use_graph
-    torch.manual_seed(99 + rank)                         # device Philox stream for the noise
-
     # ---- synthetic conditions of this rank's shard, resident in HBM
     lo, hi = D.shard_bounds(args.bs * world, rank, world)
+    # noise keyed by GLOBAL sample index (dmh_rng_indexed inside the captured denoise step): row i of the N-rank job is
+    # row i of the 1-GPU job, whatever N is (the reference's N hand-started processes all draw the same default stream)
+    D.key_noise_by_sample(diffusion, 99, args.bs * world, device=device)
     conds = ddpm.SyntheticConditions(args.image_size, hi - lo, seed=1000 + lo, device=device)
     data, classes = next(conds)
     rgb_flow, flow, mask = data[:, -5:-2].contiguous(), data[:, -2:].contiguous(), data[:, -6:-5].contiguous()
@@ -323,7 +325,8 @@ def main():
                                        '(non-BASELINE configuration)'),
                        'global_batch': args.bs * world, 'sharding': f'samples x{world}, no data-path collective',
                        'cfg_mode': args.cfg_mode, 'hip_graph': use_graph,
-                       'weights': 'seeded random init', 'noise': 'device Philox',
+                       'weights': 'seeded random init',
+                       'noise': 'Philox4x32-10 keyed by (seed, global sample id, draw, element): dmh_rng_indexed, rows invariant to N',
                        'arithmetic': 'fp32 tensors; 3x3 / 1x1 convolutions and the attention projections multiply block-scaled '
                                      'fp16 pieces of the fp32 operands on the matrix cores (3 MFMAs per product block, '
                                      'fp32 accumulate, error at the fp32-accumulation level: DESIGN.md 3.1); '

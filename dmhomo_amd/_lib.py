@@ -20,7 +20,7 @@ c_int = C.c_int
 c_float = C.c_float
 
 
-ABI_VERSION = 302          # include/dmhomo_hip.h: DMH_ABI_VERSION
+ABI_VERSION = 400          # include/dmhomo_hip.h: DMH_ABI_VERSION
 
 
 class DmhConv(C.Structure):
@@ -131,6 +131,12 @@ SIGNATURES = {
     'dmh_sampler_step_dev': (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_void_p]),
     'dmh_sampler_seek': (c_int, [C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int,
                                  C.c_void_p]),
+    'dmh_rng_indexed': (c_int, [c_f32p, c_int, c_i64, C.c_void_p, C.c_void_p, c_int, C.c_void_p]),
+    'dmh_rows_lincomb': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_i64, c_int, C.c_void_p]),
+    'dmh_pixel_grid': (c_int, [c_f32p, c_int, c_int, c_int, c_float, C.c_void_p]),
+    'dmh_norm_grid': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_homography_flow_points': (c_int, [C.c_void_p, C.c_void_p, C.c_void_p, c_int, c_int, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_dlt_points': (c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int, c_int, C.c_void_p]),
     'dmh_affine': (c_int, [c_f32p, c_f32p, c_float, c_float, c_i64, C.c_void_p]),
     'dmh_affine_tail': (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_float, c_float, C.c_void_p]),
     'dmh_q_sample': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_i64, C.c_void_p]),

@@ -16,7 +16,7 @@ from . import _params as P
 from . import ops
 from ._lib import DmhStep
 from .engine import UnetEngine
-from .schedule import make_buffers, ddim_pairs
+from .schedule import make_buffers, ddim_pairs, linear_beta_schedule, cosine_beta_schedule  # noqa: F401
 
 ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
 
@@ -31,14 +31,77 @@ def default(val, d):
     return d() if callable(d) else d
 
 
+def extract(a, t, x_shape):
+    """D3, CFG:472-475: a.gather(-1, t) shaped (b, 1, ..., 1) (integer indexing: tensor plumbing)."""
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
 class DeviceRng:
-    """draws with torch's generator of the target device, in the reference's call order
-    (CFG:679 randn(shape), CFG:90 zeros(B).uniform_(0,1), CFG:703 randn_like)."""
+    """The noise source of the samplers, drawn in the reference's call order (CFG:679 randn(shape), CFG:90
+    zeros(B).uniform_(0,1), CFG:703 randn_like).
+
+    Default: torch's generator of the target device — the reference's own behaviour: row b of a draw depends on how many
+    rows the process holds and on the process's seed.
+    After ``key_by_sample(seed, sample_ids)``: every value is a pure function of (seed, GLOBAL sample id, draw index,
+    element) (``dmh_rng_indexed``: Philox4x32-10 + Box-Muller; the draw index lives in device memory and advances with
+    every launch, also inside a replayed HIP graph) — a batch sharded over N ranks, each keyed with its own slice of the
+    sample ids, reproduces the single-GPU batch row for row, bit for bit."""
+
+    def __init__(self):
+        self.sample_ids = None           # (B,) int64 device tensor once keyed
+        self.state = None                # (4,) int64 device tensor: seed, draw index, tickets, reserved
+
+    def key_by_sample(self, seed, sample_ids, device=None):
+        """sample_ids: the GLOBAL indices of this process's rows (``range(lo, hi)`` of distributed.shard_bounds), in row
+        order.  Re-keying with the same number of rows on the same device keeps the tensors' storage (a captured graph
+        stays valid) and restarts the draw index at 0."""
+        ids = torch.as_tensor(list(sample_ids), dtype=torch.int64)
+        device = torch.device(device) if device is not None else (self.sample_ids.device if self.sample_ids is not None
+                                                                 else torch.device('cuda', torch.cuda.current_device()))
+        state = torch.tensor([int(seed), 0, 0, 0], dtype=torch.int64)
+        if self.sample_ids is not None and self.sample_ids.shape == ids.shape and self.sample_ids.device == device:
+            self.sample_ids.copy_(ids)
+            self.state.copy_(state)
+        else:
+            self.sample_ids, self.state = ids.to(device), state.to(device)
+        return self
+
+    def unkey(self):
+        self.sample_ids = self.state = None
+        return self
+
+    @property
+    def keyed(self):
+        return self.sample_ids is not None
+
+    def graph_key(self):
+        """what a captured launch of this generator bakes in"""
+        return None if not self.keyed else (self.sample_ids.data_ptr(), self.state.data_ptr(), int(self.sample_ids.shape[0]))
+
+    def snapshot(self, device):
+        """state to put back with ``restore`` (the eager warm-up in front of a graph capture must not consume draws)"""
+        if self.keyed:
+            return ('indexed', self.state.clone())
+        return ('stream', torch.cuda.get_rng_state(device))
+
+    def restore(self, snap, device):
+        if snap[0] == 'indexed':
+            self.state.copy_(snap[1])
+        else:
+            torch.cuda.set_rng_state(snap[1], device)
 
     def randn(self, shape, device):
+        if self.keyed:
+            assert int(shape[0]) == self.sample_ids.shape[0], (tuple(shape), self.sample_ids.shape)
+            return ops.rng_indexed(shape, self.sample_ids, self.state, 0)
         return torch.randn(tuple(shape), device=device)
 
     def uniform(self, n, device):
+        if self.keyed:
+            assert int(n) == self.sample_ids.shape[0], (n, self.sample_ids.shape)
+            return ops.rng_indexed((n,), self.sample_ids, self.state, 1)
         return torch.zeros((n,), device=device).float().uniform_(0, 1)
 
 
@@ -180,14 +243,26 @@ class Unet(nn.Module):
         cond_out.index_copy_(0, seld, out[:n])
         return cond_out, null_out
 
-    def forward_with_cond_scale(self, x, time, classes, rgb_flow, mask, cond_scale=1.):
+    def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
+        """CFG:403-410: ``forward(*args, **kwargs)``; for cond_scale != 1 blended with ``forward(*args, cond_drop_prob=1.,
+        **kwargs)`` — so, as in the reference, a caller's own ``cond_drop_prob`` is accepted only with cond_scale == 1."""
         if cond_scale == 1:
-            return self.forward(x, time, classes, rgb_flow, mask)
+            return self.forward(*args, **kwargs)
+        if 'cond_drop_prob' in kwargs or len(args) > 5:
+            raise TypeError("forward() got multiple values for keyword argument 'cond_drop_prob'")   # as CFG:409 would
+        x, time, classes, rgb_flow, mask = _bind_forward(self.forward, args, kwargs)
         logits, null = self._cond_null(x, time, classes, rgb_flow, mask)
         step = DmhStep(objective=ops.OBJECTIVE['pred_x0'], clip=0, mode=ops.MODE_LAST, cond_scale=float(cond_scale),
                        sqrt_recip_ac=1., sqrt_recipm1_ac=1.)
         out, _, _ = ops.sampler_step(step, logits, null, logits, None, want_x_start=False)
         return out
+
+
+def _bind_forward(forward, args, kwargs):
+    import inspect
+    ba = inspect.signature(forward).bind(*args, **kwargs)           # TypeError for missing / unknown arguments, like a call
+    a = ba.arguments
+    return a['x'], a['time'], a['classes'], a['rgb_flow'], a['mask']
 
 
 class ScheduleHost:
@@ -208,6 +283,53 @@ class ScheduleHost:
             cache = (sig, {n: getattr(self, n).detach().cpu() for n in self._HOST_NAMES})
             self.__dict__['_host_cache'] = cache
         return cache[1]
+
+    # ---- D4 / D7: the affine combinations of CFG:586-608 [DDP:584-611] with a timestep per row
+    def _at(self, name, t, neg=False):
+        a = getattr(self, name)
+        return (-a if neg else a).gather(-1, t.to(torch.int64)).contiguous()
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        """CFG:586-588: extract(sqrt_recip_ac) * x_t - extract(sqrt_recipm1_ac) * noise."""
+        return ops.rows_lincomb(x_t, self._at('sqrt_recip_alphas_cumprod', t), noise,
+                                self._at('sqrt_recipm1_alphas_cumprod', t, neg=True))
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        """CFG:590-594: (extract(sqrt_recip_ac) * x_t - x0) / extract(sqrt_recipm1_ac)."""
+        minus_one = torch.full((x_t.shape[0],), -1., device=x_t.device, dtype=torch.float32)
+        return ops.rows_lincomb(x_t, self._at('sqrt_recip_alphas_cumprod', t), x0, minus_one,
+                                div=self._at('sqrt_recipm1_alphas_cumprod', t))
+
+    def predict_v(self, x_start, t, noise):
+        """CFG:596-598: extract(sqrt_ac) * noise - extract(sqrt_1m_ac) * x_start."""
+        return ops.rows_lincomb(noise, self._at('sqrt_alphas_cumprod', t), x_start,
+                                self._at('sqrt_one_minus_alphas_cumprod', t, neg=True))
+
+    def predict_start_from_v(self, x_t, t, v):
+        """CFG:600-601: extract(sqrt_ac) * x_t - extract(sqrt_1m_ac) * v."""
+        return ops.rows_lincomb(x_t, self._at('sqrt_alphas_cumprod', t), v,
+                                self._at('sqrt_one_minus_alphas_cumprod', t, neg=True))
+
+    def q_posterior(self, x_start, x_t, t):
+        """CFG:603-608: (posterior mean, variance, clipped log variance), the last two shaped (b, 1, 1, 1)."""
+        mean = ops.rows_lincomb(x_start, self._at('posterior_mean_coef1', t), x_t, self._at('posterior_mean_coef2', t))
+        return (mean, extract(self.posterior_variance, t, x_t.shape),
+                extract(self.posterior_log_variance_clipped, t, x_t.shape))
+
+    def _predictions_per_row(self, model_output, x, t, clip_x_start):
+        """the objective branch of model_predictions (CFG:614-628) for a batch whose rows sit at different timesteps"""
+        one = torch.ones((x.shape[0],), device=x.device, dtype=torch.float32)
+        clip = (lambda v: ops.rows_lincomb(v, one, clamp=True)) if clip_x_start else (lambda v: v)
+        if self.objective == 'pred_noise':
+            pred_noise = model_output
+            x_start = clip(self.predict_start_from_noise(x, t, pred_noise))
+        elif self.objective == 'pred_x0':
+            x_start = clip(model_output)
+            pred_noise = self.predict_noise_from_start(x, t, x_start)
+        else:                                                # pred_v
+            x_start = clip(self.predict_start_from_v(x, t, model_output))
+            pred_noise = self.predict_noise_from_start(x, t, x_start)
+        return ModelPrediction(pred_noise, x_start)
 
     def _ddim_coef(self, host, time, time_next):
         """sqrt(alpha_next), c, sigma in the reference's op order, CFG:697-701."""
@@ -263,11 +385,12 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                        sqrt_1m_ac=float(host['sqrt_one_minus_alphas_cumprod'][t]),
                        c0=float(c[0]), c1=float(c[1]), c2=float(c[2]))
 
-    def _uniform_time(self, t):
-        """python int when every sample shares the timestep (always true while sampling)."""
+    @staticmethod
+    def _uniform_time(t):
+        """python int when every row shares the timestep (always true while sampling), else None"""
         t0 = int(t[0])
         if t.numel() > 1 and not bool((t == t0).all()):
-            raise NotImplementedError('dmhomo_amd.model_predictions expects one timestep per batch (as the samplers use)')
+            return None
         return t0
 
     def _network(self, x, t, classes, rgb_flow, mask, cond_scale):
@@ -276,16 +399,52 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         return self.model._cond_null(x, t, classes, rgb_flow, mask)
 
     def model_predictions(self, x, t, classes, rgb_flow, mask, cond_scale=3., clip_x_start=False):
-        """CFG:610-630."""
+        """CFG:610-630.  One timestep for the whole batch (what the samplers pass): blend, objective branch and clamp in
+        ONE pass of dmh_sampler_step; a timestep per row (p_losses-style callers): the same arithmetic row by row."""
         host = self._host()
         cond, null = self._network(x, t, classes, rgb_flow, mask, cond_scale)
-        step = self._step(host, self._uniform_time(t), ops.MODE_LAST, cond_scale, clip_x_start)
+        t0 = self._uniform_time(t)
+        if t0 is None:
+            if null is not None:                             # null + (cond - null) * cond_scale, CFG:410
+                blend = DmhStep(objective=ops.OBJECTIVE['pred_x0'], clip=0, mode=ops.MODE_LAST,
+                                cond_scale=float(cond_scale), sqrt_recip_ac=1., sqrt_recipm1_ac=1.)
+                cond, _, _ = ops.sampler_step(blend, cond, null, cond, None, want_x_start=False)
+            return self._predictions_per_row(cond, x.contiguous(), t, clip_x_start)
+        step = self._step(host, t0, ops.MODE_LAST, cond_scale, clip_x_start)
         _, x_start, pred_noise = ops.sampler_step(step, cond, null, x.contiguous(), None, True, True)
         return ModelPrediction(pred_noise, x_start)
 
+    def p_mean_variance(self, x, t, classes, cond_scale, clip_denoised=True):
+        """CFG:632-637 as it stands: it hands model_predictions ``(x, t, classes, cond_scale)`` — cond_scale in rgb_flow's
+        place and no mask — so the call raises TypeError.  Kept failing at the same call."""
+        preds = self.model_predictions(x, t, classes, cond_scale)
+        x_start = preds.pred_x_start
+        if clip_denoised:
+            x_start.clamp_(-1., 1.)
+        model_mean, posterior_variance, posterior_log_variance = self.q_posterior(x_start=x_start, x_t=x, t=t)
+        return model_mean, posterior_variance, posterior_log_variance, x_start
+
     @torch.no_grad()
-    def ddim_sample(self, classes, rgb_flow, flow, mask, shape, cond_scale=3., clip_denoised=True, trace=None):
-        """CFG:669-711.  ``trace`` (list) optionally receives per-step x_start / img for parity tests."""
+    def p_sample(self, x, t: int, classes, cond_scale=3., clip_denoised=True):
+        """CFG:639-654: one ancestral step through p_mean_variance — which raises (above), as in the reference."""
+        batched_times = torch.full((x.shape[0],), t, device=x.device, dtype=torch.long)
+        model_mean, _, model_log_variance, x_start = self.p_mean_variance(x=x, t=batched_times, classes=classes,
+                                                                          cond_scale=cond_scale,
+                                                                          clip_denoised=clip_denoised)
+        b = x.shape[0]
+        one = torch.ones((b,), device=x.device, dtype=torch.float32)
+        if not t > 0:
+            return model_mean, x_start
+        noise = self.rng.randn(x.shape, x.device)
+        return ops.rows_lincomb(model_mean, one, noise, (0.5 * model_log_variance).exp().reshape(b)), x_start
+
+    @torch.no_grad()
+    def ddim_sample(self, classes, rgb_flow, flow, mask, shape, cond_scale=3., clip_denoised=True):
+        """CFG:669-711."""
+        return self._ddim_sample(classes, rgb_flow, flow, mask, shape, cond_scale, clip_denoised)
+
+    def _ddim_sample(self, classes, rgb_flow, flow, mask, shape, cond_scale=3., clip_denoised=True, trace=None):
+        """ddim_sample; ``trace`` (list) optionally receives per-step x_start / img for parity tests."""
         batch, device = shape[0], self.betas.device
         host = self._host()
         img = self.rng.randn(shape, device).contiguous()
@@ -331,7 +490,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         shape = (batch_size, channels, image_size, image_size)
         if not self.is_ddim_sampling:
             return self.p_sample_loop(classes, rgb_flow, flow, mask, shape, cond_scale)    # TypeError, as CFG:719-720
-        if self.hip_graph and type(self.rng) is DeviceRng:
+        if self.hip_graph and type(self.rng) is DeviceRng and self.sampling_timesteps >= 1:
             return self._sample_graphed(classes, rgb_flow, flow, mask, shape, cond_scale)
         rgb_flow = ops.affine(rgb_flow.to(torch.float32), 2., -1.)      # normalize_to_neg_one_to_one, CFG:716
         return self.ddim_sample(classes, rgb_flow, flow, mask, shape, cond_scale)
@@ -346,7 +505,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         key = (tuple(shape), tuple(rgb_flow.shape), float(cond_scale), self.model.cfg_mode, int(self.model.stream_splits),
                bool(self.model.dedup_dropped_rows), bool(self.model.share_first_conv), float(self.model.cond_drop_prob), eng._sig, self.sampling_timesteps,
                self.num_timesteps, self.objective, float(self.ddim_sampling_eta), clip, self.__dict__['_host_cache'][0],
-               str(device))
+               str(device), self.rng.graph_key())
         st = self.__dict__.get('_graph_state')
         if st is None or st['key'] != key:
             if self.model.dedup_dropped_rows:
@@ -380,7 +539,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
             # eager warm-up of both bodies on a side stream (first-launch work: LDS attributes, side streams), as
             # torch.cuda.graphs asks for; the device RNG state is put back afterwards, so the capturing call consumes
             # exactly what an eager sample() would
-            rng_state = torch.cuda.get_rng_state(device)
+            rng_state = self.rng.snapshot(device)
             ops.affine(ins[1], 2., -1., out=st['rf'])
             ops.sampler_seek(cursor, 0, table, tt, cur, st['tcond'])
             side = torch.cuda.Stream(device=device)
@@ -396,7 +555,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
             g_last = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_last, pool=g_mid.pool(), capture_error_mode='thread_local'):
                 st['out'] = last()
-            torch.cuda.set_rng_state(rng_state, device)
+            self.rng.restore(rng_state, device)
             st['graph'], st['graph_last'] = g_mid, g_last
             self.__dict__['_graph_state'] = st
         for dst, src in zip(st['ins'], (classes, rgb_flow, mask)):

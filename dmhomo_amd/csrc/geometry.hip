@@ -249,3 +249,167 @@ extern "C" int dmh_dlt_homography(const float* flow, double* ws, double* Hout, i
   DMH_CHECK_LAUNCH("dmh_dlt_homography(solve)");
   return DMH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// The helper functions around G2 / G4 / G5 that scripts import by name: get_grid DDP:1558-1574,
+// norm_grid DDP:1292-1299, the multi-band / arbitrary-index get_flow_np DDP:927-969, DLT_solve DDP:1577-1644 on explicit
+// point sets.
+__global__ __launch_bounds__(256) void pixel_grid_kernel(float* __restrict__ out, int H, int W, float start) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const size_t hw = (size_t)H * W;
+  out[((size_t)b * 2 + 0) * hw + p] = (float)(p % W) + start;
+  out[((size_t)b * 2 + 1) * hw + p] = (float)(p / W) + start;
+}
+
+// v (B,2,H,W) -> (B,H,W,2): 2.0 * v / (W-1) - 1.0 (x), 2.0 * v / (H-1) - 1.0 (y), fp32 in that op order
+__global__ __launch_bounds__(256) void norm_grid_kernel(const float* __restrict__ v, float* __restrict__ out, int H, int W) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const size_t hw = (size_t)H * W;
+  const float gx = 2.0f * v[((size_t)b * 2 + 0) * hw + p] / (float)(W - 1) - 1.0f;
+  const float gy = 2.0f * v[((size_t)b * 2 + 1) * hw + p] / (float)(H - 1) - 1.0f;
+  out[((size_t)b * hw + p) * 2 + 0] = gx;
+  out[((size_t)b * hw + p) * 2 + 1] = gy;
+}
+
+// get_flow_np: Hm (B, divide, 3, 3) f64, idx (Bi, 3, H, W) f64 (Bi == B or 1), flow (B, 2, H, W) f64.  Row y uses the
+// homography of band min(y / (H / divide), divide - 1) (DDP:940-951); w' += 1e-6 unconditionally (DDP:958-959).
+__global__ __launch_bounds__(256) void homography_flow_points_kernel(const double* __restrict__ Hm, const double* __restrict__ idx,
+                                                                     double* __restrict__ flow, int divide, int Bi, int H,
+                                                                     int W) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const size_t hw = (size_t)H * W;
+  const int band_h = H / divide;
+  int band = band_h > 0 ? (p / W) / band_h : 0;
+  band = band < divide - 1 ? band : divide - 1;
+  const double* h = Hm + ((size_t)b * divide + band) * 9;
+  const double* ip = idx + (size_t)(Bi == 1 ? 0 : b) * 3 * hw + p;
+  const double x = ip[0], y = ip[hw], o = ip[2 * hw];
+  const double qx = h[0] * x + h[1] * y + h[2] * o;
+  const double qy = h[3] * x + h[4] * y + h[5] * o;
+  const double qw = (h[6] * x + h[7] * y + h[8] * o) + 1e-6;
+  flow[((size_t)b * 2 + 0) * hw + p] = qx / qw - x;
+  flow[((size_t)b * 2 + 1) * hw + p] = qy / qw - y;
+}
+
+// DLT on explicit correspondences: src, off (N, P, 2) f64; system n: least squares over its P points (dst = src + off)
+__global__ __launch_bounds__(256) void dlt_accumulate_points_kernel(const double* __restrict__ src, const double* __restrict__ off,
+                                                                    double* __restrict__ ws, int P) {
+  __shared__ double red[4][44];
+  const int b = blockIdx.y, blk = blockIdx.x;
+  double acc[44];
+#pragma unroll
+  for (int i = 0; i < 44; ++i) acc[i] = 0.0;
+  for (int p = blk * 256 + threadIdx.x; p < P; p += DMH_DLT_BLOCKS * 256) {
+    const size_t q = ((size_t)b * P + p) * 2;
+    const double x = src[q], y = src[q + 1];
+    const double xd = x + off[q], yd = y + off[q + 1];
+    const double ru[8] = {x, y, 1.0, 0.0, 0.0, 0.0, -xd * x, -xd * y};
+    const double rv[8] = {0.0, 0.0, 0.0, x, y, 1.0, -yd * x, -yd * y};
+    dlt_accum(acc, ru, xd);
+    dlt_accum(acc, rv, yd);
+  }
+#pragma unroll
+  for (int i = 0; i < 44; ++i) {
+    double v = acc[i];
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    acc[i] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 44; ++i) red[wave][i] = acc[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 44)
+    ws[((size_t)b * DMH_DLT_BLOCKS + blk) * 44 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// P == 4: the 8x8 system is square — solved as it stands (Gaussian elimination with partial pivoting, f64) instead of
+// through its normal equations, which would square the condition number of an exactly determined system
+__global__ void dlt_solve4_kernel(const double* __restrict__ src, const double* __restrict__ off, double* __restrict__ Hout,
+                                  int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double A[8][9];
+  for (int p = 0; p < 4; ++p) {
+    const size_t q = ((size_t)n * 4 + p) * 2;
+    const double x = src[q], y = src[q + 1];
+    const double xd = x + off[q], yd = y + off[q + 1];
+    const double ru[9] = {x, y, 1.0, 0.0, 0.0, 0.0, -xd * x, -xd * y, xd};
+    const double rv[9] = {0.0, 0.0, 0.0, x, y, 1.0, -yd * x, -yd * y, yd};
+    for (int j = 0; j < 9; ++j) {
+      A[2 * p][j] = ru[j];
+      A[2 * p + 1][j] = rv[j];
+    }
+  }
+  for (int c = 0; c < 8; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < 8; ++r)
+      if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+    for (int j = 0; j < 9; ++j) {
+      const double t = A[c][j];
+      A[c][j] = A[piv][j];
+      A[piv][j] = t;
+    }
+    const double d = A[c][c];
+    for (int r = c + 1; r < 8; ++r) {
+      const double f = A[r][c] / d;
+      for (int j = c; j < 9; ++j) A[r][j] -= f * A[c][j];
+    }
+  }
+  double h[8];
+  for (int i = 7; i >= 0; --i) {
+    double t = A[i][8];
+    for (int j = i + 1; j < 8; ++j) t -= A[i][j] * h[j];
+    h[i] = t / A[i][i];
+  }
+  for (int i = 0; i < 8; ++i) Hout[(size_t)n * 9 + i] = h[i];
+  Hout[(size_t)n * 9 + 8] = 1.0;
+}
+
+extern "C" int dmh_pixel_grid(float* out, int B, int H, int W, float start, void* stream) {
+  DMH_REQUIRE(out && B > 0 && H > 0 && W > 0, "dmh_pixel_grid: bad arguments");
+  hipLaunchKernelGGL(pixel_grid_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, out, H, W, start);
+  DMH_CHECK_LAUNCH("dmh_pixel_grid");
+  return DMH_OK;
+}
+
+extern "C" int dmh_norm_grid(const float* v, float* out, int B, int H, int W, void* stream) {
+  DMH_REQUIRE(v && out && B > 0 && H > 0 && W > 0, "dmh_norm_grid: bad arguments");
+  hipLaunchKernelGGL(norm_grid_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, v, out, H, W);
+  DMH_CHECK_LAUNCH("dmh_norm_grid");
+  return DMH_OK;
+}
+
+extern "C" int dmh_homography_flow_points(const double* Hm, const double* idx, double* flow, int B, int divide, int Bi, int H,
+                                          int W, void* stream) {
+  DMH_REQUIRE(Hm && idx && flow && B > 0 && divide > 0 && H >= divide && W > 0 && (Bi == 1 || Bi == B),
+              "dmh_homography_flow_points: bad arguments");
+  hipLaunchKernelGGL(homography_flow_points_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, Hm, idx,
+                     flow, divide, Bi, H, W);
+  DMH_CHECK_LAUNCH("dmh_homography_flow_points");
+  return DMH_OK;
+}
+
+extern "C" int dmh_dlt_points(const double* src, const double* off, double* ws, double* Hout, int N, int P, void* stream) {
+  DMH_REQUIRE(src && off && ws && Hout && N > 0 && P >= 4, "dmh_dlt_points: bad arguments (N systems of P >= 4 points)");
+  DMH_REQUIRE(N <= 65535, "dmh_dlt_points: N=%d systems (limit 65535 per call)", N);
+  hipStream_t st = (hipStream_t)stream;
+  if (P == 4) {
+    hipLaunchKernelGGL(dlt_solve4_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, src, off, Hout, N);
+    DMH_CHECK_LAUNCH("dmh_dlt_points(4-point solve)");
+    return DMH_OK;
+  }
+  hipLaunchKernelGGL(dlt_accumulate_points_kernel, dim3(DMH_DLT_BLOCKS, N), dim3(256), 0, st, src, off, ws, P);
+  DMH_CHECK_LAUNCH("dmh_dlt_points(accumulate)");
+  hipLaunchKernelGGL(dlt_solve_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, ws, Hout, N);
+  DMH_CHECK_LAUNCH("dmh_dlt_points(solve)");
+  return DMH_OK;
+}

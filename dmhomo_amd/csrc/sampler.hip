@@ -218,6 +218,22 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__
   }
 }
 
+// out = ca[b] * x (+ cb[b] * y) (/ dv[b]) (clamped to [-1, 1]): the per-sample affine combinations of CFG:586-608 with a
+// timestep per row, in the reference's op order (two rounded products, one add, one divide)
+__global__ __launch_bounds__(256) void rows_lincomb_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ ca, const float* __restrict__ cb,
+                                                           const float* __restrict__ dv, float* __restrict__ out,
+                                                           int64_t per_sample, int64_t total, int clamp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int b = (int)(i / per_sample);
+    float v = ca[b] * x[i];
+    if (y) v = v + cb[b] * y[i];
+    if (dv) v = v / dv[b];
+    if (clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+    out[i] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ x, float* __restrict__ y, float scale,
                                                      float shift, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -390,5 +406,15 @@ extern "C" int dmh_to_uint8(const float* img, uint8_t* out, int64_t n, void* str
   DMH_REQUIRE(img && out && n > 0, "dmh_to_uint8: bad arguments");
   hipLaunchKernelGGL(to_uint8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, img, out, n);
   DMH_CHECK_LAUNCH("dmh_to_uint8");
+  return DMH_OK;
+}
+
+extern "C" int dmh_rows_lincomb(const float* x, const float* y, const float* ca, const float* cb, const float* dv, float* out,
+                                int B, int64_t per_sample, int clamp, void* stream) {
+  DMH_REQUIRE(x && ca && out && B > 0 && per_sample > 0 && (!y || cb), "dmh_rows_lincomb: bad arguments");
+  const int64_t total = (int64_t)B * per_sample;
+  hipLaunchKernelGGL(rows_lincomb_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, ca, cb, dv, out,
+                     per_sample, total, clamp);
+  DMH_CHECK_LAUNCH("dmh_rows_lincomb");
   return DMH_OK;
 }

@@ -16,9 +16,9 @@ from torch import nn
 from . import _params as P
 from . import ops
 from ._lib import DmhStep
-from .cfg import DeviceRng, ModelPrediction, ScheduleHost, default, exists
+from .cfg import DeviceRng, ModelPrediction, ScheduleHost, default, exists, extract  # noqa: F401
 from .engine import UnetEngine
-from .schedule import make_buffers, ddim_pairs
+from .schedule import make_buffers, ddim_pairs, linear_beta_schedule, cosine_beta_schedule  # noqa: F401
 
 __version__ = '0.1.0'
 
@@ -97,17 +97,34 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                        c0=float(c[0]), c1=float(c[1]), c2=float(c[2]))
 
     def model_predictions(self, x, t, x_self_cond=None, clip_x_start=False):
-        """DDP:613-634 (one timestep per batch, as every sampler uses it)."""
-        t0 = int(t[0])
+        """DDP:613-634 (one timestep per batch, as every sampler uses it: one fused pass; a timestep per row: row by row)."""
         out = self.model(x, t, x_self_cond)
+        t0 = self._uniform_time(t)
+        if t0 is None:
+            return self._predictions_per_row(out, x.contiguous(), t, clip_x_start)
         step = self._step(self._host(), t0, ops.MODE_LAST, clip_x_start)
         _, x_start, pred_noise = ops.sampler_step(step, out, None, x.contiguous(), None, True, True)
         return ModelPrediction(pred_noise, x_start)
 
+    @staticmethod
+    def _uniform_time(t):
+        t0 = int(t[0])
+        return None if (t.numel() > 1 and not bool((t == t0).all())) else t0
+
+    def p_mean_variance(self, x, t, x_self_cond=None, clip_denoised=True):
+        """DDP:636-645: (posterior mean, variance, clipped log variance, x_start) of one ancestral step."""
+        preds = self.model_predictions(x, t, x_self_cond)
+        x_start = preds.pred_x_start
+        if clip_denoised:
+            x_start = ops.rows_lincomb(x_start, torch.ones((x.shape[0],), device=x.device, dtype=torch.float32),
+                                       clamp=True)
+        model_mean, posterior_variance, posterior_log_variance = self.q_posterior(x_start=x_start, x_t=x, t=t)
+        return model_mean, posterior_variance, posterior_log_variance, x_start
+
     @torch.no_grad()
-    def p_sample(self, x, t: int, x_self_cond=None, clip_denoised=True, _host=None):
+    def p_sample(self, x, t: int, x_self_cond=None, clip_denoised=True):
         """DDP:647-661: one ancestral step -> (pred_img, x_start)."""
-        host = _host or self._host()
+        host = self._host()                                   # (cached per buffer version)
         bt = torch.full((x.shape[0],), t, device=x.device, dtype=torch.long)
         out = self.model(x, bt, x_self_cond)
         # exp(0.5 * logvar) as fp32 0-dim tensor arithmetic, DDP:660
@@ -127,7 +144,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         x_start = None
         for t in reversed(range(0, self.num_timesteps)):
             self_cond = x_start if self.self_condition else None
-            img, x_start = self.p_sample(img, t, self_cond, _host=host)
+            img, x_start = self.p_sample(img, t, self_cond)
         img = ops.affine(img, 0.5, 0.5)
         ops.affine_tail_(img, img.shape[1] - 2, 2., -1.)          # flow channels back to [-1, 1], DDP:679
         return img
@@ -172,7 +189,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         img = ops.lerp(xt1, xt2, float(lam))                               # (1 - lam) * xt1 + lam * xt2
         host = self._host()
         for i in reversed(range(0, t)):
-            img, _ = self.p_sample(img, i, _host=host)
+            img, _ = self.p_sample(img, i)
         return img
 
     def q_sample(self, x_start, t, noise=None):
@@ -263,6 +280,68 @@ def homo_to_flow(homo, H=600, W=800):
     flow, _ = ops.homography_flow(torch.as_tensor(np.asarray(homo), dtype=torch.float64).reshape(1, 3, 3)
                                   .to(_dev()).contiguous(), H, W, 256., want_rgb=False)
     return flow[0].permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+def mesh_grid_np(B, H, W):
+    """DDP:913-924: (B,3,H,W) integer homogeneous pixel coordinates (x, y, 1) (host numpy, as in the reference)."""
+    x_base = np.tile(np.arange(0, W), (B, H, 1))
+    y_base = np.tile(np.arange(0, H), (B, W, 1)).transpose(0, 2, 1)
+    return np.stack([x_base, y_base, np.ones_like(x_base)], 1)
+
+
+def get_flow_np(H_mat_mul, patch_indices, image_size_h=600, image_size_w=800):
+    """DDP:927-969: ``divide`` homographies (batch, divide, 3, 3)-shaped, one per horizontal band of the image, applied to
+    the homogeneous coordinates ``patch_indices`` (B,3,H,W) in float64 (w' + 1e-6, DDP:958-959) -> flow, squeezed and
+    laid out (H, W, 2) as the reference returns it (dmh_homography_flow_points)."""
+    H_mat_mul = np.asarray(H_mat_mul, dtype=np.float64)
+    batch_size, divide = H_mat_mul.shape[0], H_mat_mul.shape[1]
+    Hm = torch.from_numpy(np.ascontiguousarray(H_mat_mul.reshape(batch_size, divide, 3, 3))).to(_dev())
+    idx = torch.from_numpy(np.ascontiguousarray(np.asarray(patch_indices, dtype=np.float64))).to(_dev())
+    assert idx.shape[2:] == (image_size_h, image_size_w), (idx.shape, image_size_h, image_size_w)
+    flow = ops.homography_flow_points(Hm, idx).cpu().numpy()
+    return flow.squeeze().transpose(1, 2, 0)
+
+
+def mesh_grid(B, H, W):
+    """DDP:1283-1289: (B,2,H,W) int64 pixel coordinates (x, y) — on the host, like the reference's (its caller moves it
+    with ``.type_as(x)``; the product's flow_warp never materialises it)."""
+    x_base = torch.arange(0, W).repeat(B, H, 1)
+    y_base = torch.arange(0, H).repeat(B, W, 1).transpose(1, 2)
+    return torch.stack([x_base, y_base], 1)
+
+
+def norm_grid(v_grid):
+    """DDP:1292-1299: pixel coordinates (B,2,H,W) -> grid_sample coordinates (B,H,W,2) in [-1, 1] (dmh_norm_grid)."""
+    return ops.norm_grid(v_grid.to(torch.float32))
+
+
+def get_grid(batch_size, H, W, start=0):
+    """DDP:1558-1574: (B,2,H,W) fp32 pixel coordinates + start, on the GPU (dmh_pixel_grid)."""
+    return ops.pixel_grid(batch_size, H, W, start, _dev())
+
+
+def DLT_solve(src_p, off_set):
+    """DDP:1577-1644: src_p, off_set (bs, n, P, 2) -> (bs, n', 3, 3) homographies.  With a (divide+1)^2 mesh of points
+    (n = 2 (divide+1)^2 coordinates laid out as the reference's index arithmetic expects) every mesh cell's four corners
+    are gathered (tensor indexing) into its own 4-point system; with n == 1 (homo_gen) the P points are one least-squares
+    system.  Solved in float64 by dmh_dlt_points."""
+    bs = src_p.shape[0]
+    divide = int(np.sqrt(len(src_p[0]) / 2) - 1)
+    row_num = (divide + 1) * 2
+    src_ps, off_sets = src_p, off_set
+    cells = []
+    for i in range(divide):
+        for j in range(divide):
+            k = 2 * j + row_num * i
+            cells.append([k, k + 1, k + 2, k + 3, k + 2 + row_num, k + 3 + row_num, k + row_num, k + row_num + 1])
+    if cells:
+        src_ps = torch.cat([src_p[:, c].reshape(bs, 1, 4, 2) for c in cells], dim=1)
+        off_sets = torch.cat([off_set[:, c].reshape(bs, 1, 4, 2) for c in cells], dim=1)
+    bs, n, h, w = src_ps.shape
+    dev = _dev()
+    src64 = src_ps.reshape(bs * n, h, w).to(device=dev, dtype=torch.float64)
+    off64 = off_sets.reshape(bs * n, h, w).to(device=dev, dtype=torch.float64)
+    return ops.dlt_points(src64, off64).reshape(bs, n, 3, 3)
 
 
 def flow_warp(x, flow12, pad='border', mode='bilinear'):

@@ -148,22 +148,27 @@ def gather_records(imgs_u8, homos, dst=0):
     return (torch.cat([t[:n] for t, n in zip(out_i, sizes)]), torch.cat([t[:n] for t, n in zip(out_h, sizes)]))
 
 
-class SampleIndexedRng:
-    """noise keyed by GLOBAL sample index: sample i always draws from its own generator seeded
-    ``seed * 1_000_003 + i``, so a sharded run reproduces the single-GPU run row for row
-    (drop-in for dmhomo_amd.cfg.DeviceRng)."""
+def noise_key(seed, total, rank, world, first_id=0):
+    """(seed, global sample ids of ``rank``'s rows) — the key every rank derives for the sample-indexed generator
+    (``cfg.DeviceRng.key_by_sample`` -> dmh_rng_indexed): the SAME seed everywhere, ids = first_id + this rank's contiguous
+    slice of ``range(total)``.  The concatenation over ranks is ``first_id + range(total)``, so an N-rank run draws, row for
+    row, what one process holding all ``total`` rows draws."""
+    lo, hi = shard_bounds(total, rank, world)
+    return int(seed), range(first_id + lo, first_id + hi)
 
-    def __init__(self, seed, sample_ids, device):
-        self.gens = []
-        for i in sample_ids:
-            g = torch.Generator(device=device)
-            g.manual_seed(seed * 1_000_003 + int(i))
-            self.gens.append(g)
 
-    def randn(self, shape, device):
-        assert shape[0] == len(self.gens)
-        return torch.stack([torch.randn(tuple(shape[1:]), generator=g, device=device) for g in self.gens])
+def key_noise_by_sample(diffusion, seed, total, first_id=0, device=None):
+    """key ``diffusion.rng`` for this process's shard of a global batch of ``total`` samples (rank / world from the process
+    group; one process: the whole batch).  Replaces the reference's per-process stream generator (CFG:679,705,90; N
+    hand-started processes of DGM/dgm_sample.py:13-18 all start from the same default seed)."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    seed, ids = noise_key(seed, total, rank, world, first_id)
+    diffusion.rng.key_by_sample(seed, ids, device)
+    return ids
 
-    def uniform(self, n, device):
-        assert n == len(self.gens)
-        return torch.cat([torch.rand((1,), generator=g, device=device) for g in self.gens])
+
+def SampleIndexedRng(seed, sample_ids, device):
+    """a generator keyed by global sample index (drop-in for a diffusion's ``.rng``): ``cfg.DeviceRng`` after
+    ``key_by_sample`` — one dmh_rng_indexed launch per draw, graph-capturable."""
+    from .cfg import DeviceRng
+    return DeviceRng().key_by_sample(seed, sample_ids, device)

@@ -391,6 +391,17 @@ def sampler_step_dev(cur, model_cond, model_null, x, noise, out=None):
     return img
 
 
+def rng_indexed(shape, sample_ids, state, kind=0):
+    """one draw of the sample-indexed generator (dmh_rng_indexed): (B, *shape[1:]) fp32 whose row b is a pure function of
+    (state[0] = seed, sample_ids[b], state[1] = draw index, element); the launch advances the draw index.
+    kind 0: N(0,1) (CFG:679,705), 1: uniform [0,1) (CFG:90), 2: the raw Philox words (bit patterns; tests)."""
+    B = int(shape[0])
+    assert sample_ids.shape == (B,) and state.shape == (4,) and state.dtype == torch.int64
+    out = torch.empty(tuple(shape), device=sample_ids.device, dtype=F32)
+    call('dmh_rng_indexed', ptr(out), B, out.numel() // B, ptr(sample_ids, torch.int64), ptr(state, torch.int64), int(kind))
+    return out
+
+
 def affine(x, scale, shift, out=None):
     x = x.contiguous()
     y = torch.empty_like(x) if out is None else out
@@ -416,6 +427,18 @@ def q_sample(x_start, noise, ca, cb):
     out = torch.empty_like(x_start)
     B = x_start.shape[0]
     call('dmh_q_sample', ptr(x_start), ptr(noise), ptr(ca), ptr(cb), ptr(out), B, x_start.numel() // B)
+    return out
+
+
+def rows_lincomb(x, ca, y=None, cb=None, div=None, clamp=False):
+    """out = ca[b] * x (+ cb[b] * y) (/ div[b]) (clamped to [-1, 1]); ca / cb / div: (B,) fp32 per-sample coefficients
+    (``extract`` of a schedule buffer at a per-row timestep): D4 / D7 of SURVEY 8a in the reference's op order."""
+    x = x.contiguous()
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    call('dmh_rows_lincomb', ptr(x), ptr(None if y is None else y.contiguous()), ptr(ca.contiguous()),
+         ptr(None if cb is None else cb.contiguous()), ptr(None if div is None else div.contiguous()), ptr(out), B,
+         x.numel() // B, int(bool(clamp)))
     return out
 
 
@@ -471,6 +494,44 @@ def flow_warp(x, flow, want_indices=False):
     return (out, x0, y0) if want_indices else out
 
 
+def pixel_grid(B, H, W, start, device):
+    """get_grid DDP:1558-1574: (B,2,H,W) fp32 pixel coordinates (+ start)."""
+    out = torch.empty((B, 2, H, W), device=device, dtype=F32)
+    call('dmh_pixel_grid', ptr(out), B, H, W, float(start))
+    return out
+
+
+def norm_grid(v):
+    """norm_grid DDP:1292-1299: (B,2,H,W) pixel coordinates -> (B,H,W,2) in [-1,1]."""
+    B, two, H, W = v.shape
+    assert two == 2
+    out = torch.empty((B, H, W, 2), device=v.device, dtype=F32)
+    call('dmh_norm_grid', ptr(v.contiguous()), ptr(out), B, H, W)
+    return out
+
+
+def homography_flow_points(Hm, idx):
+    """get_flow_np DDP:927-969: Hm (B,divide,3,3) f64, idx (Bi,3,H,W) f64 -> flow (B,2,H,W) f64."""
+    B, divide = Hm.shape[:2]
+    Bi, three, H, W = idx.shape
+    assert three == 3 and Hm.shape[2:] == (3, 3)
+    out = torch.empty((B, 2, H, W), device=Hm.device, dtype=torch.float64)
+    call('dmh_homography_flow_points', ptr(Hm.contiguous(), torch.float64), ptr(idx.contiguous(), torch.float64),
+         ptr(out, torch.float64), B, divide, Bi, H, W)
+    return out
+
+
+def dlt_points(src, off):
+    """DLT_solve DDP:1612-1643: src, off (N,P,2) f64 -> (N,3,3) f64 least-squares homographies."""
+    N, P, two = src.shape
+    assert two == 2 and off.shape == src.shape
+    ws = torch.empty((N, _lib.DLT_BLOCKS, 44), device=src.device, dtype=torch.float64)
+    out = torch.empty((N, 3, 3), device=src.device, dtype=torch.float64)
+    call('dmh_dlt_points', ptr(src.contiguous(), torch.float64), ptr(off.contiguous(), torch.float64),
+         ptr(ws, torch.float64), ptr(out, torch.float64), N, P)
+    return out
+
+
 def dlt_homography(flow):
     """G5: flow (B,2,H,W) fp32 -> (B,3,3) f64."""
     B, _, H, W = flow.shape
@@ -519,7 +580,10 @@ def conv_dgrad_pack(w, c_in_total, batch=None):
         return _DgradPacked(w, c_in_total, batch)
     wt = w.detach().flip(2, 3).transpose(0, 1).contiguous()          # (Cin, Cout, k, k)
     assert wt.shape[0] == c_in_total
-    return PackedConv(wt, None, w.shape[0])
+    if batch is not None:            # (exact-fp32 variants: no table-driven pack) re-made from w on every batch.run()
+        w_src = w.detach()
+        batch.pre.append(lambda: wt.copy_(w_src.flip(2, 3).transpose(0, 1)))
+    return PackedConv(wt, None, w.shape[0], batch=batch)
 
 
 def gn_finalize_train(stats, gamma, beta, hw, groups, ss=None, eps=1e-5):

@@ -15,17 +15,25 @@ BUFFER_ORDER = (
     'posterior_mean_coef1', 'posterior_mean_coef2', 'p2_loss_weight')
 
 
+def linear_beta_schedule(timesteps):
+    """CFG:478-482 / DDP:460-464 (float64, host)."""
+    k = 1000 / timesteps
+    return torch.linspace(k * 1e-4, k * 2e-2, timesteps, dtype=torch.float64)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    """CFG:485-495 / DDP:467-478 (float64, host): abar = cos^2(((x / T) + s) / (1 + s) * pi / 2), normalised at 0."""
+    grid = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64)
+    abar = torch.cos((grid / timesteps + s) / (1 + s) * math.pi * 0.5) ** 2
+    abar = abar / abar[0]
+    return torch.clip(1 - abar[1:] / abar[:-1], 0, 0.999)
+
+
 def betas_for(name, timesteps):
-    f64 = torch.float64
     if name == 'linear':
-        k = 1000 / timesteps
-        return torch.linspace(k * 1e-4, k * 2e-2, timesteps, dtype=f64)
+        return linear_beta_schedule(timesteps)
     if name == 'cosine':
-        s = 0.008
-        grid = torch.linspace(0, timesteps, timesteps + 1, dtype=f64)
-        abar = torch.cos((grid / timesteps + s) / (1 + s) * math.pi * 0.5) ** 2
-        abar = abar / abar[0]
-        return torch.clip(1 - abar[1:] / abar[:-1], 0, 0.999)
+        return cosine_beta_schedule(timesteps)
     raise ValueError(f'unknown beta schedule {name}')
 
 

@@ -36,10 +36,18 @@ class ResnetBlockTrain:
         p = self.p
         cout = p['w1'].shape[0]
         self.cout = cout
-        if batch is not None:
+        if batch is not None and ops._batchable(3, 1, 0):
             self.w1s, self.w2s = torch.empty_like(p['w1']), torch.empty_like(p['w2'])
             self.f1 = ops.PackedConv(self.w1s, p['b1'], self.c0, self.c1, batch=batch, ws_from=p['w1'])
             self.f2 = ops.PackedConv(self.w2s, p['b2'], cout, batch=batch, ws_from=p['w2'])
+        elif batch is not None:
+            # DMH_CONV3_VARIANT selects the exact-fp32 kernels: dmh_pack_conv_weights_multi does not make their images, so
+            # the standardised weights are written into fixed buffers ahead of the per-weight pack launches
+            self.w1s, self.w2s = ops.ws_standardize(p['w1']), ops.ws_standardize(p['w2'])
+            batch.pre.append(lambda: (self.w1s.copy_(ops.ws_standardize(self.p['w1'])),
+                                      self.w2s.copy_(ops.ws_standardize(self.p['w2']))))
+            self.f1 = ops.PackedConv(self.w1s, p['b1'], self.c0, self.c1, batch=batch)
+            self.f2 = ops.PackedConv(self.w2s, p['b2'], cout, batch=batch)
         else:
             self.w1s, self.w2s = ops.ws_standardize(p['w1']), ops.ws_standardize(p['w2'])
             self.f1 = ops.PackedConv(self.w1s, p['b1'], self.c0, self.c1)
@@ -623,8 +631,12 @@ class TrainStep:
 
     def refresh(self):
         """re-pack the training kernels' weight images from the (updated / loaded) parameters"""
+        ptrs = tuple(p.data_ptr() for p in self.params.values())
+        if self._repack_graph not in (None, False) and ptrs != getattr(self, '_graph_ptrs', None):
+            self._repack_graph = None                      # parameter storage moved since the capture: its pointers are stale
         if self._repack_graph is None:
             self.ut.refresh()                              # (re)build: buffers, the pack table, a first fill
+            self._graph_ptrs = ptrs
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()

@@ -36,7 +36,7 @@ extern "C" {
 const char* dmh_last_error(void);
 /* DMH_ABI_VERSION of the library: bumped whenever a struct layout or an entry point changes; a binding must refuse a
  * library whose version differs from the header it was written against (dmhomo_amd/_lib.py does). */
-#define DMH_ABI_VERSION 302
+#define DMH_ABI_VERSION 400
 int dmh_version(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -258,10 +258,27 @@ int dmh_sampler_step_dev(const DmhStep* cur_dev, const float* model_cond, const 
 int dmh_sampler_seek(int32_t* cursor, int k, const DmhStep* table, const int64_t* times, int S, DmhStep* cur,
                      int64_t* tcond, int B, void* stream);
 
+/* Noise of the sampling loop keyed by GLOBAL sample index: replaces torch.randn(shape) CFG:679,
+ * torch.randn_like(img) CFG:705 and torch.zeros(B).uniform_(0, 1) CFG:90 where a run is sharded over ranks.
+ * out [B][per_sample]: element e of row b = f(seed, sample_ids[b], draw, e) with f = Philox4x32-10 (key = seed, counter =
+ * (e / 4, draw, sample id lo, hi)) followed by Box-Muller (kind 0: N(0,1)), the top 24 bits * 2^-24 (kind 1: uniform
+ * [0,1)) or nothing (kind 2: the raw 32-bit words as float bit patterns, for known-answer tests) — so any row is the
+ * same whichever rank, batch size or row position computes it.
+ * state: 4 x uint64 in DEVICE memory: [0] seed, [1] draw index — read by every workgroup, advanced by one by the last
+ * workgroup of the launch to finish, so a captured launch replays with the next draw —, [2] arrival tickets (0 between
+ * launches), [3] reserved.  sample_ids: [B] int64. */
+int dmh_rng_indexed(float* out, int B, int64_t per_sample, const int64_t* sample_ids, uint64_t* state, int kind,
+                    void* stream);
+
 /* y = x*scale + shift elementwise (normalize / unnormalize, CFG:69-74) */
 int dmh_affine(const float* x, float* y, float scale, float shift, int64_t n, void* stream);
 /* in place on channels >= c0 of an NCHW tensor: x = x*scale + shift (flow channel remap, DDP:679,728) */
 int dmh_affine_tail(float* x, int B, int C, int HW, int c0, float scale, float shift, void* stream);
+/* D4 / D7 with a timestep per row: out = ca[b]*x (+ cb[b]*y) (/ dv[b]) (clamped to [-1,1] when clamp != 0); y, cb, dv may be
+ * NULL.  predict_start_from_noise / predict_noise_from_start / predict_v / predict_start_from_v CFG:586-601, the posterior
+ * mean of q_posterior CFG:603-608 and the optional clamp of model_predictions CFG:612, in the reference's op order */
+int dmh_rows_lincomb(const float* x, const float* y, const float* ca, const float* cb, const float* dv, float* out, int B,
+                     int64_t per_sample, int clamp, void* stream);
 /* D9 q_sample CFG:738-742: out = ca[b]*x_start + cb[b]*noise, ca/cb = extract(sqrt_ac / sqrt_1m_ac, t) */
 int dmh_q_sample(const float* x_start, const float* noise, const float* ca, const float* cb, float* out, int B,
                  int64_t per_sample, void* stream);
@@ -288,6 +305,18 @@ int dmh_flow_to_image(const float* flow, float* rgb, int B, int HW, float max_fl
  * x0/y0 (NULL or int32 [B][H][W]) receive the top-left corner indices (bit-exact contract). */
 int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, int32_t* y0, int B, int C, int H,
                   int W, void* stream);
+/* get_grid DDP:1558-1574: out (B,2,H,W) fp32 = (x + start, y + start) of every pixel */
+int dmh_pixel_grid(float* out, int B, int H, int W, float start, void* stream);
+/* norm_grid DDP:1292-1299: v (B,2,H,W) -> out (B,H,W,2) = (2.0*v_x/(W-1) - 1.0, 2.0*v_y/(H-1) - 1.0), fp32, that op order */
+int dmh_norm_grid(const float* v, float* out, int B, int H, int W, void* stream);
+/* get_flow_np DDP:927-969 in its general form: Hm (B,divide,3,3) f64 — row y uses band min(y / (H/divide), divide-1) —,
+ * idx (Bi,3,H,W) f64 homogeneous coordinates (Bi == B or 1: mesh_grid_np), flow (B,2,H,W) f64 = H.p / (w' + 1e-6) - p */
+int dmh_homography_flow_points(const double* Hm, const double* idx, double* flow, int B, int divide, int Bi, int H, int W,
+                               void* stream);
+/* DLT_solve DDP:1612-1643 on explicit correspondences: src, off (N,P,2) f64 -> Hout (N,3,3) f64, one least-squares
+ * homography per system (P == 4: the square system solved directly; P > 4: f64 normal equations as dmh_dlt_homography);
+ * ws: [N][DMH_DLT_BLOCKS][44] f64 (unused for P == 4) */
+int dmh_dlt_points(const double* src, const double* off, double* ws, double* Hout, int N, int P, void* stream);
 /* G5  homo_gen / DLT_solve DDP:1577-1661 through f64 normal equations; ws: [B][DMH_DLT_BLOCKS][44] f64 */
 #define DMH_DLT_BLOCKS 64
 int dmh_dlt_homography(const float* flow, double* ws, double* Hout, int B, int H, int W, void* stream);

@@ -12,7 +12,8 @@ Differences from the reference script (DGM/dgm_sample.py:11-101), all forced by 
   * multi-GPU: launch with torch.distributed.run instead of N hand-started processes (--gpu_nums / -i are
     still accepted and select the data slice exactly as the reference's unused arguments did: not at all); rank 0
     alone reads the checkpoint and broadcasts the online + EMA weights over RCCL (the reference's N processes each
-    load the file, SAMPLE:54); sampling replays one captured denoise step from a HIP graph.
+    load the file, SAMPLE:54); sampling replays one captured denoise step from a HIP graph; noise is keyed by --seed and
+    the global sample index (dmh_rng_indexed), so N processes produce the records one process would.
 Output: traindata/<exp>/dataset/idx_<i>_rank_<r>_part_<p>_dm_cahomo_<k>k.npy — a pickled list of
 {"imgs": uint8 (B,6,H,W), "homos": float64 (B,3,3)} every 2 batches (SAMPLE:73-77), the format
 HEM/dataset/data_loader.py:123-131 consumes.
@@ -40,6 +41,7 @@ parser.add_argument('-i', type=int, default=0)
 parser.add_argument('--image_size', type=int, default=256)        # SAMPLE:32 hard-codes 256
 parser.add_argument('--batches', type=int, default=2)
 parser.add_argument('--conditions', type=str, default=None)
+parser.add_argument('--seed', type=int, default=0, help='noise seed (every value is keyed by seed and global sample index)')
 args = parser.parse_args()
 
 num_classes = 1
@@ -67,7 +69,11 @@ def main():
     out_dir = f'traindata/{args.exp}/dataset/'
     os.makedirs(out_dir, exist_ok=True)
     train_list, part = [], args.part
-    for _ in range(args.batches):
+    for b in range(args.batches):
+        # noise keyed by (seed, GLOBAL sample index): rank r of N draws rows [b*bs*N + r*bs, +bs) of the job's noise, so
+        # the records do not depend on how many processes made them (the reference's N hand-started processes all start
+        # from the same default generator state, SAMPLE:13-18: every process draws the SAME noise)
+        D.key_noise_by_sample(sampler, args.seed, args.bs * world, first_id=b * args.bs * world, device=device)
         ret = trainer.sample(args.i, device, step=len(train_list))
         train_list.append(ret)
         print(f'length of trainList {len(train_list)}')

@@ -33,9 +33,13 @@ def _worker(rank, world, port, q):
     imgs = torch.arange(slo, shi, dtype=torch.uint8).reshape(-1, 1, 1, 1).expand(-1, 6, 2, 2).contiguous()
     homos = torch.arange(slo, shi, dtype=torch.float64).reshape(-1, 1, 1).expand(-1, 3, 3).contiguous()
     gi, gh = D.gather_records(imgs, homos, dst=0)
-    rng = D.SampleIndexedRng(7, range(slo, shi), device)
-    n1 = rng.randn((shi - slo, 2, 3), device)
-    u1 = rng.uniform(shi - slo, device)
+    # the key each rank derives for the sample-indexed noise generator (dmh_rng_indexed needs the GPU; its numpy
+    # restatement stands in for the values here): same seed, this rank's slice of the global sample ids
+    from oracle import rng as ORNG
+    seed, ids = D.noise_key(7, total, rank, world, first_id=1000)
+    assert seed == 7 and list(ids) == list(range(1000 + slo, 1000 + shi))
+    n1 = torch.from_numpy(ORNG.randn(seed, ids, 5, (2, 3)))
+    u1 = torch.from_numpy(ORNG.uniform(seed, ids, 6)[:, 0])
     # training: gradient averaging (the scale step is a HIP kernel on the GPU path; a torch multiply stands in here)
     grads = {'b.weight': torch.full((2, 3), float(rank + 1)), 'a.bias': torch.arange(4.) * (rank + 1)}
     avg = D.average_gradients(grads, lambda flat, sc: flat * sc)
@@ -71,9 +75,12 @@ def test_world2_gloo():
     assert b0 == (0, 3) and b1 == (3, 5)                # contiguous, first ranks take the remainder
     assert gi0 == [0, 1, 2, 3, 4, 5, 6] and gh0 == [0., 1., 2., 3., 4., 5., 6.] and gi1 is None
     from dmhomo_amd import distributed as D
-    full = D.SampleIndexedRng(7, range(0, 7), torch.device('cpu'))
-    assert torch.equal(torch.tensor(n0 + n1), full.randn((7, 2, 3), torch.device('cpu')))
-    assert torch.equal(torch.tensor(u0 + u1), full.uniform(7, torch.device('cpu')))
+    # N-rank noise == the single-process noise, row for row: the ranks' keys concatenate to the one-process key
+    from oracle import rng as ORNG
+    seed, ids = D.noise_key(7, 7, 0, 1, first_id=1000)
+    assert list(ids) == list(D.noise_key(7, 7, 0, 2, first_id=1000)[1]) + list(D.noise_key(7, 7, 1, 2, first_id=1000)[1])
+    assert torch.equal(torch.tensor(n0 + n1), torch.from_numpy(ORNG.randn(seed, ids, 5, (2, 3))))
+    assert torch.equal(torch.tensor(u0 + u1), torch.from_numpy(ORNG.uniform(seed, ids, 6)[:, 0]))
 
 
 def _ckpt_worker(rank, world, port, q, folder):

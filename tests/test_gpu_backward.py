@@ -593,3 +593,22 @@ def test_conv_wgrad_dynamic_range(ops):
         for kx in range(3):
             r = ((dw[:, :, ky, kx].double().cpu() - gw[:, :, ky, kx]).abs().max() / gw[:, :, ky, kx].abs().max()).item()
             assert r < 5e-6, (ky, kx, r)
+
+
+@pytest.mark.parametrize('variant', ['0', '6'])
+def test_training_under_exact_fp32_conv_variants_in_child_process(variant):
+    """DMH_CONV3_VARIANT != 9 (the exact-fp32 forward kernels; read once per process): the training step builds — the
+    table-driven weight re-pack only makes the fp16-piece images, so the standardised weights and the data-gradient
+    weights go through fixed buffers + per-weight pack launches — and follows the reference's gradients and its 6-step
+    optimiser trajectory (which needs every image re-made after every update)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMH_CONV3_VARIANT=variant)
+    here = os.path.join(root, 'tests', 'test_gpu_backward.py')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        here + '::test_train_step_gradients_vs_reference', here + '::test_train_trajectory_vs_reference'],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -224,7 +224,7 @@ def test_ddim_trace_vs_golden(golden_dir, obj):
     shape = (2, 6, 16, 16)
     from dmhomo_amd import ops
     rgbn = ops.affine(g(T(gd['rgb_flow01'])), 2., -1.)
-    img, mk, fl = d.ddim_sample(g(T(gd['classes'])), rgbn, g(T(gd['flow'])), g(T(gd['mask'])), shape, trace=trace)
+    img, mk, fl = d._ddim_sample(g(T(gd['classes'])), rgbn, g(T(gd['flow'])), g(T(gd['mask'])), shape, trace=trace)
     tol = 3e-4                                        # measured: x_start <= 3.9e-5, img <= 1.4e-5 (all three objectives)
     for i, st in enumerate(trace):
         close(f'{obj} x_start{i}', st['x_start'].cpu(), T(gd[f'{obj}.x_start{i}']), rtol=0, atol=tol)
@@ -300,7 +300,7 @@ def test_ddim_trace_s32_vs_golden(golden_dir, S):
     trace = []
     from dmhomo_amd import ops
     rgbn = ops.affine(g(T(gd[f's{S}.rgb_flow01'])), 2., -1.)
-    img, _, _ = d.ddim_sample(g(T(gd[f's{S}.classes'])), rgbn, g(T(gd[f's{S}.flow'])), g(T(gd[f's{S}.mask'])),
+    img, _, _ = d._ddim_sample(g(T(gd[f's{S}.classes'])), rgbn, g(T(gd[f's{S}.flow'])), g(T(gd[f's{S}.mask'])),
                               (2, 6, S, S), trace=trace)
     assert d.rng.i == 64 and len(trace) == 32
     drift = [float((st['x_start'].cpu() - T(gd[f's{S}.x_start{i}'])).abs().max()) for i, st in enumerate(trace)]
@@ -334,7 +334,7 @@ def test_sample_fullsize_s32_vs_oracle():
     d.rng = ReplayDeviceRng(rec.draws)
     trace = []
     rgbn = ops.affine(g(rf01), 2., -1.)
-    img, _, _ = d.ddim_sample(g(c), rgbn, g(flow), g(mk), (B, 6, 128, 128), trace=trace)
+    img, _, _ = d._ddim_sample(g(c), rgbn, g(flow), g(mk), (B, 6, 128, 128), trace=trace)
     drift = [float((a['x_start'].cpu() - b['x_start']).abs().max()) for a, b in zip(trace, rtrace)]
     print('[parity] sample S=32 full size: per-step max|x_start - oracle| = ' + ' '.join(f'{e:.1e}' for e in drift))
     close('sample S=32 full', img.cpu(), ref, rtol=0, atol=2e-4)

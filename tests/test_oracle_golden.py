@@ -302,3 +302,19 @@ def test_warp_known_answers():
     assert torch.equal(OG.flow_warp(pow2, torch.zeros(1, 2, 5, 9)), pow2)
     ix, iy, x0, y0 = OG.warp_coords(torch.full((1, 2, 9, 13), 100.))
     assert int(x0.min()) == 12 and int(y0.min()) == 8                        # border clamp
+
+
+def test_philox_known_answers():
+    """oracle/rng.py (the restatement of dmh_rng_indexed's generator) against Random123's kat_vectors for philox4x32
+    with 10 rounds, and the properties the sharded sampler relies on: a row is a function of its sample id alone."""
+    from oracle import rng as R
+    for ctr, key, want in R.KAT:
+        got = R.philox4x32_10(np.array([ctr], dtype=np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == want
+    whole = R.randn(7, range(10), 3, (2, 5))
+    assert np.array_equal(np.concatenate([R.randn(7, range(0, 4), 3, (2, 5)), R.randn(7, range(4, 10), 3, (2, 5))]), whole)
+    assert not np.array_equal(R.randn(7, range(10), 4, (2, 5)), whole) and not np.array_equal(R.randn(8, range(10), 3, (2, 5)), whole)
+    z = R.randn(1, range(64), 0, (4096,)).astype(np.float64)
+    assert abs(z.mean()) < 1e-2 and abs(z.std() - 1) < 1e-2
+    u = R.uniform(1, range(4096), 1, 4)
+    assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 1e-2
