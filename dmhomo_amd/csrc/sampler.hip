@@ -171,8 +171,9 @@ __global__ __launch_bounds__(256) void sampler_step_dev_kernel(const DmhStep* __
     }
     float o;
     if (s.mode == 0) {
-      o = x0 * s.c0 + s.c1 * pn;
-      if (noise) o = o + s.c2 * noise[i];   // (a DDIM entry always comes with noise; the table cannot be checked at launch)
+      // a DDIM entry always comes with noise; the device-resident entry cannot be checked at launch, so a mis-sequenced
+      // cursor (the last-step graph replayed on a non-last entry) shows up as NaN instead of a plausible wrong sample
+      o = x0 * s.c0 + s.c1 * pn + s.c2 * (noise ? noise[i] : __builtin_nanf(""));
     } else if (s.mode == 1) {
       o = x0;
     } else {

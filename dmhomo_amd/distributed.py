@@ -74,19 +74,30 @@ def broadcast_module_(module, src=0):
 def load_on_rank0_and_broadcast(trainer, milestone, src=0):
     """north_star's start-up: ONLY rank ``src`` reads the checkpoint from disk (``trainer.load``: online weights + EMA
     copy, DDP:1804-1826); every other rank receives both copies over RCCL — one scatter + all-gather payload each
-    (``broadcast_module_``) — instead of N processes each loading the file (README:14, DGM/dgm_sample.py:54).
+    (``broadcast_module_``) — instead of N processes each loading the file (README:14, DGM/dgm_sample.py:54), and the
+    host-side counters a resumed ``Trainer.train`` loops on (``trainer.step``, the EMA's ``step`` / ``initted``, the
+    optimiser state) as one object broadcast, so every rank runs the same number of steps.  A failing load on ``src``
+    raises on EVERY rank (the peers would otherwise sit in the next collective until it times out).
     ``milestone`` None: nothing to load, the seeded initialisation of rank ``src`` is broadcast.  -> True if a file was read."""
     rank = dist.get_rank() if world_size() > 1 else 0
-    loaded = False
+    loaded, err = False, None
     if rank == src and milestone is not None:
-        trainer.load(milestone)
-        loaded = True
+        try:
+            trainer.load(milestone)
+            loaded = True
+        except Exception as e:                               # reported to every rank below, then re-raised
+            err = e
+            if world_size() == 1:
+                raise
     if world_size() > 1:
         dev = next(trainer.model.parameters()).device
         # the EMA copy gets storage of its own only when the checkpoint's EMA weights differ from the online ones: every
         # rank has to make the same choice before the payloads travel
-        flag = torch.tensor([int(trainer.ema.ema_model is not trainer.ema.online_model), int(loaded)], device=dev)
+        flag = torch.tensor([int(trainer.ema.ema_model is not trainer.ema.online_model), int(loaded), int(err is not None)],
+                            device=dev)
         dist.broadcast(flag, src=src)
+        if bool(flag[2].item()):
+            raise RuntimeError(f'rank {src} could not load checkpoint {milestone!r}' + (f': {err!r}' if err else ''))
         if bool(flag[0].item()) and trainer.ema.ema_model is trainer.ema.online_model:
             trainer.ema._own_copy()
         broadcast_module_(trainer.model, src=src)
@@ -94,7 +105,30 @@ def load_on_rank0_and_broadcast(trainer, milestone, src=0):
             broadcast_module_(trainer.ema.ema_model, src=src)
             trainer.ema._bump()
         loaded = bool(flag[1].item())
+        if loaded:
+            opt = trainer._ts.state_dict() if trainer._ts is not None else trainer._opt_state
+            host = [dict(step=int(trainer.step), ema_step=int(trainer.ema.step), ema_initted=bool(trainer.ema.initted),
+                         opt=_to_cpu(opt))] if rank == src else [None]
+            dist.broadcast_object_list(host, src=src)
+            if rank != src:
+                trainer.step = host[0]['step']
+                trainer.ema.step.fill_(host[0]['ema_step'])
+                trainer.ema.initted.fill_(host[0]['ema_initted'])
+                if host[0]['opt'] is not None:
+                    trainer._opt_state = host[0]['opt']
+                    if trainer._ts is not None:
+                        trainer._ts.load_state_dict(trainer._opt_state)
     return loaded
+
+
+def _to_cpu(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().cpu()
+    if isinstance(obj, dict):
+        return {k: _to_cpu(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_to_cpu(v) for v in obj)
+    return obj
 
 
 def average_gradients(grads, scale):

@@ -367,6 +367,14 @@ def step_table(steps, times, device):
     """device tables of a replayed sampling loop: steps (list of DmhStep, host-computed) -> (uint8 tensor holding the
     packed structs, int64 times, int32 cursor, one-struct uint8 'current' buffer)."""
     n = len(steps)
+    # the kernels read these entries from device memory and cannot validate them at launch: do it here
+    if n < 1 or len(times) != n:
+        raise ValueError(f'step_table: {n} steps, {len(times)} times')
+    for i, st in enumerate(steps):
+        if st.objective not in (0, 1, 2) or st.mode not in (MODE_DDIM, MODE_LAST, MODE_DDPM):
+            raise ValueError(f'step_table: entry {i} has objective {st.objective} / mode {st.mode}')
+        if (st.mode == MODE_LAST) != (i == n - 1) and st.mode != MODE_DDPM:
+            raise ValueError(f'step_table: entry {i} of {n} has mode {st.mode}: MODE_LAST belongs to the last entry only')
     sz = C.sizeof(_lib.DmhStep)
     arr = (_lib.DmhStep * n)(*steps)
     raw = torch.frombuffer(bytearray(C.string_at(C.addressof(arr), n * sz)), dtype=torch.uint8).clone()

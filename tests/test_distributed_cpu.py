@@ -96,7 +96,14 @@ def _ckpt_worker(rank, world, port, q, folder):
     tr = ddpm.Trainer(d, 'DGM_Conditions', train_batch_size=2, results_folder=folder if rank == 0 else folder + '/absent')
     loaded = D.load_on_rank0_and_broadcast(tr, 7)
     dig = lambda mod: float(sum(p.double().sum() for p in mod.state_dict().values()))
-    q.put((rank, loaded, tr.ema.ema_model is not tr.ema.online_model, dig(tr.model), dig(tr.ema.ema_model)))
+    # a checkpoint that rank 0 cannot read must fail on EVERY rank (not leave the peers in a collective)
+    try:
+        D.load_on_rank0_and_broadcast(tr, 'absent')
+        failed = False
+    except (RuntimeError, FileNotFoundError):
+        failed = True
+    q.put((rank, loaded, tr.ema.ema_model is not tr.ema.online_model, dig(tr.model), dig(tr.ema.ema_model),
+           int(tr.step), int(tr.ema.step), bool(tr.ema.initted), failed))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -128,9 +135,12 @@ def test_checkpoint_is_read_by_rank0_only_and_broadcast(tmp_path):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, loaded, own, d_on, d_ema in res:
+    for rank, loaded, own, d_on, d_ema, step, ema_step, initted, failed in res:
         assert loaded and own, (rank, loaded, own)
         assert d_on == want_on and d_ema == want_ema, (rank, d_on, want_on, d_ema, want_ema)
+        # the counters a resumed Trainer.train loops on travel too, so the ranks agree on the number of steps left
+        assert (step, ema_step, initted) == (5, 5, True), (rank, step, ema_step, initted)
+        assert failed, rank
 
 
 def test_bench_launches_its_own_ranks():

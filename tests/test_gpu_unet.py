@@ -589,6 +589,40 @@ def test_stress_config_s250_graph_equals_eager():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_stress_config_at_its_stated_batch():
+    """BASELINE configs[4] AS STATED: dim 128, 256x256, s_step = 250, bs = 8, 'streams' CFG mode, per-step HIP graph, noise
+    keyed by sample index — the full 250-step run at B = 8; rows 0 and 7 are BITWISE the rows of B = 1 runs of those two
+    samples (250 replays of a 2-row step each), everything finite and inside [0, 1], rows distinct."""
+    import time
+    from dmhomo_amd import cfg
+    m = cfg.Unet(dim=128, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    m.load_state_dict(det_state_dict(shapes_of(m), 3))
+    m = m.to(dev())
+    m.cfg_mode = 'streams'
+    d = cfg.GaussianDiffusion(m, image_size=256, timesteps=1000, sampling_timesteps=250, objective='pred_x0').to(dev())
+    d.hip_graph = True
+    B = 8
+    _, rf, mk = _cond_inputs(B, 256, 850)
+    rf01, flow, c, mk = g((rf + 1) / 2), g(rand((B, 2, 256, 256), 853)), g(torch.zeros(B, dtype=torch.long)), g(mk)
+
+    def run(rows):
+        d.rng.key_by_sample(23, rows, dev())
+        sel = torch.tensor(list(rows), device=dev())
+        t0 = time.perf_counter()
+        img = d.sample(c[sel], rf01[sel].contiguous(), flow[sel].contiguous(), mk[sel].contiguous())[0].clone()
+        torch.cuda.synchronize()
+        return img, time.perf_counter() - t0
+    whole, sec = run(range(B))
+    print(f'[parity] configs[4] bs=8 s_step=250 (incl. capture): {sec:.1f} s = {sec / 250 * 1e3:.1f} ms per denoise step')
+    assert whole.shape == (B, 6, 256, 256) and torch.isfinite(whole).all()
+    assert float(whole.min()) >= 0 and float(whole.max()) <= 1
+    for r in (0, 7):
+        one, _ = run([r])
+        assert torch.equal(one[0], whole[r]), r
+    assert not torch.equal(whole[0], whole[7])
+    d.rng.unkey()
+
+
 def test_unet_ddp_fullsize_vs_oracle():
     """unconditional UNet (pixel-unshuffle Downsample, self-conditioning) at dim=64, 128x128"""
     m, sd = make_ddp(64, True)
