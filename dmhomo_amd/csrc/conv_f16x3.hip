@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int kg = lane >> 4;   // K group (8 channels) of this lane's A / B fragment slice; row group of its C slice
   const int l15 = lane & 15;  // fragment row (pixel) / column (output channel)
   const int wm = wave / WN, wn = wave % WN;
@@ -324,6 +325,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     if (pro) {
 #pragma unroll
       for (int i = 0; i < NLOAD; ++i) {
+        // the last load group is only partly populated (16 x 16 tile: 32 of its 256 lanes): the waves that hold none of it
+        // skip its eight transcendentals — a scalar branch (the wave index is uniform), not an exec-masked region
+        if ((i + 1) * 256 > IN_PIX * NQ && ((wave_u * 64 + i * 256) >> QS) >= IN_PIX) continue;
         v[i].x = silu_fast(fmaf(ca.x, v[i].x, cb.x));
         v[i].y = silu_fast(fmaf(ca.y, v[i].y, cb.y));
         v[i].z = silu_fast(fmaf(ca.z, v[i].z, cb.z));
@@ -886,7 +890,12 @@ int dmh_f16x3_launch(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
     return wide ? launch_f16x3<3, 3, 1, 1, 8, 16, 2, 2>(d, Hout, Wout, st)
                 : launch_f16x3<3, 3, 1, 1, 16, 16, 4, 1>(d, Hout, Wout, st);
   }
-  if (wide) return launch_f16x3<3, 3, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st);
+  static int wide3 = -1;  // development knob (DMH_F16_WIDE3=0: the 16x16x64 layout for every plain 3x3)
+  if (wide3 < 0) {
+    const char* e = getenv("DMH_F16_WIDE3");
+    wide3 = e ? atoi(e) : 1;
+  }
+  if (wide && wide3) return launch_f16x3<3, 3, 1, 0, 8, 16, 2, 2>(d, Hout, Wout, st);
   // (the 16 x 16 layout keeps a load's source pixel relative to the tile in 16 bits: PACKPW in the kernel)
   DMH_REQUIRE(17 * (int64_t)d->Win + 17 < 65536, "dmh_conv2d: 3x3 with Cout %% 128 != 0 supports Win <= 3853 (got %d)", d->Win);
   return launch_f16x3<3, 3, 1, 0, 16, 16, 4, 1>(d, Hout, Wout, st);

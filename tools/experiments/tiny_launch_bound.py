@@ -1,0 +1,103 @@
+"""probe (round 4): what the tiny launches between the big kernels cost the HEADLINE step — an upper bound for folding them
+into their producers.  The headline runs the two CFG passes on two streams and replays a HIP graph, so a 5 us launch on one
+stream sits under the other stream's convolution: its price is not its duration.  Here each family is REMOVED from the
+captured step (its outputs are cached from an eager warm-up call per call site, so every other kernel sees the same shapes
+and realistic values) and the step is timed against the unmodified one, alternating, same box, same process.
+
+    python tools/experiments/tiny_launch_bound.py            (families: gn_finalize, linattn merge, both)
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+from dmhomo_amd import cfg, ddpm, ops
+from dmhomo_amd import _lib
+
+dev = torch.device('cuda', 0)
+ABLATE = set()
+cache = {}
+real_gn, real_call = ops.gn_finalize, ops.call
+
+
+def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5, want_bound=False):
+    if 'gn' not in ABLATE:
+        return real_gn(stats, gamma, beta, hw, groups, ss, eps, want_bound)
+    key = ('gn', tuple(stats.shape), gamma.data_ptr(), want_bound, torch.cuda.current_stream().cuda_stream)
+    if key not in cache:
+        cache[key] = real_gn(stats, gamma, beta, hw, groups, ss, eps, want_bound)
+    return cache[key]
+
+
+def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None):
+    """ops.linear_attention_fused with the merge launch optionally replaced by a context cached per call site"""
+    from dmhomo_amd.ops import _empty, ptr, lib
+    B, H, W, c = x.shape
+    n = H * W
+    if stats is None:
+        stats = _empty((B, n, 2), x)
+        real_call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, c, float(eps))
+    ns = lib().dmh_linattn_fused_splits(B, n)
+    partial = _empty((B, ns, 4, 1088), x)
+    real_call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c)
+    key = ('merge', tuple(x.shape), pla.wpack.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    if 'merge' in ABLATE and key in cache:
+        ctx = cache[key]
+    else:
+        ctx = _empty((B, 4, 32, 32), x)
+        real_call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
+        if 'merge' in ABLATE:
+            cache[key] = ctx
+    if out is not None:
+        y = _empty((B, H, W, 64), x)
+        real_call('dmh_linattn_fused_apply_out', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(out.wpack),
+                  ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps))
+        return y
+    o = _empty((B, H, W, 128), x)
+    real_call('dmh_linattn_fused_apply', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(o), B, n, c, float(scale))
+    return o
+
+
+ops.gn_finalize = gn_finalize
+ops.linear_attention_fused = linear_attention_fused
+caches = {}
+
+
+def build(name, ablate):
+    global cache
+    ABLATE.clear()
+    ABLATE.update(ablate)
+    cache = caches.setdefault(name, {})                  # (kept alive: the captured step reads these tensors)
+    torch.manual_seed(0)
+    model = cfg.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    model.cfg_mode = 'streams'
+    d = cfg.GaussianDiffusion(model, image_size=128, timesteps=1000, sampling_timesteps=32, loss_type='l1',
+                              objective='pred_x0').to(dev)
+    d.hip_graph = True
+    d.rng.key_by_sample(99, range(25), dev)
+    return d
+
+
+conds = ddpm.SyntheticConditions(128, 25, seed=1000, device=dev)
+data, classes = next(conds)
+rgb_flow, flow, mask = data[:, -5:-2].contiguous(), data[:, -2:].contiguous(), data[:, -6:-5].contiguous()
+variants = [('baseline', ()), ('no gn_finalize', ('gn',)), ('no linattn merge', ('merge',)), ('neither', ('gn', 'merge'))]
+models = {}
+for name, abl in variants:
+    d = build(name, abl)
+    d.sample(classes, rgb_flow, flow, mask)               # eager warm-up inside + capture (with this variant's ablation set)
+    torch.cuda.synchronize()
+    models[name] = (d, set(abl))
+for rnd in range(3):
+    for name, (d, abl) in models.items():
+        ABLATE.clear()
+        ABLATE.update(abl)
+        cache = caches[name]
+        d.sample(classes, rgb_flow, flow, mask)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            d.sample(classes, rgb_flow, flow, mask)
+        torch.cuda.synchronize()
+        print(f'round {rnd} {name:18s}: {75 / (time.perf_counter() - t0):.2f} images/s', flush=True)
