@@ -131,3 +131,37 @@ def test_soak_deep_conv_two_streams(ops):
             torch.cuda.current_stream().wait_stream(s)
         bad += sum(int(not torch.equal(o, alone)) for o in outs)
     assert bad == 0, f'{bad} launches differ'
+
+
+@pytest.mark.parametrize('B', [25, 50])
+def test_soak_ring_kernel_beside_a_conv_240_launches(ops, B):
+    """pass 1 of the fused LinearAttention at C = 64 / 128x128 — linattn_kv_ring_kernel, the LDS-DMA ring with raw barriers,
+    a sibling of round 3's software-pipelined form that was bitwise right alone and wrong in 58 of 60 launches beside a
+    convolution on a second stream (unexplained; tools/experiments/README.md) — on its own: 240 launches with a conv
+    running beside it, EVERY word of the per-split (max, sum, context) partials of all rows bitwise equal to the launch made
+    on an idle chip.  (The build-time counterpart: tests/test_isa_hazards.py checks that every barrier of the kernel is
+    reached with none of the wave's DMA pieces in flight.)"""
+    from dmhomo_amd.ops import _empty, ptr, call, lib
+    C, H = 64, 128
+    n = H * H
+    gq = (1 + 0.2 * rand((C,), 61)).to(dev())
+    pla = ops.PackedLinAttn(rand((384, C, 1, 1), 62, C ** -0.5).to(dev()))
+    x = (rand((B, H, H, C), 63) * 1.3 + 0.2).to(dev())
+    stats = _empty((B, n, 2), x)
+    call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, C, 1e-5)
+    ns = lib().dmh_linattn_fused_splits(B, n)
+
+    def context():
+        partial = torch.zeros((B, ns, 4, 1088), device=dev())
+        call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(gq), ptr(pla.wpack), ptr(partial), B, n, C)
+        return partial
+    torch.cuda.synchronize()
+    alone = context()
+    torch.cuda.synchronize()
+    nb = _Neighbour(ops, 'conv')
+    bad = 0
+    for _ in range(240):
+        nb.kick()
+        bad += int(not torch.equal(context(), alone))
+    nb.join()
+    assert bad == 0, f'{bad} of 240 launches differ from the launch on an idle chip'

@@ -23,3 +23,47 @@ def test_no_inline_asm_hazards_in_generated_isa(src, tmp_path):
                     os.path.join(ROOT, 'dmhomo_amd', 'csrc', src), '-o', out], check=True, capture_output=True, timeout=900)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'hazard_scan.py'), out], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip().endswith('findings: 0'), r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_lds_dma_ring_every_barrier_sees_the_waves_own_pieces_landed(tmp_path):
+    """round 4 (the unexplained under-load fault of round 3's software-pipelined ring, tools/experiments/README.md): the
+    shipped LDS-DMA ring kernel (linattn_kv_ring_kernel) must reach every s_barrier with NONE of the wave's vector-memory
+    operations in flight — at most one unit (five pieces) at the priming barrier — and set M0 directly in front of every
+    global_load_lds: a forward dataflow over the kernel's control-flow graph in the generated code
+    (tools/hazard_scan.py::scan_lds_dma).  The checker is itself checked on a synthetic violation."""
+    if not os.path.exists(HIPCC):
+        pytest.skip('hipcc not present')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import hazard_scan
+    out = str(tmp_path / 'linattn_fused.s')
+    subprocess.run([HIPCC, '-O3', '-std=c++17', '--offload-arch=gfx950', '-S', '--cuda-device-only',
+                    os.path.join(ROOT, 'dmhomo_amd', 'csrc', 'linattn_fused.hip'), '-o', out], check=True, capture_output=True,
+                   timeout=900)
+    text = open(out).read()
+    assert 'global_load_lds_dwordx4' in text                         # the ring kernel is in there
+    assert hazard_scan.scan_lds_dma(out) == 0
+    # negative controls: a barrier behind an unwaited DMA issue (loop carried), and a DMA issue without its M0 set-up
+    bad = tmp_path / 'bad.s'
+    bad.write_text('''
+bad_kernel:
+\ts_mov_b32 m0, s4
+\ts_nop 0
+\tglobal_load_lds_dwordx4 v[0:1], off
+\ts_waitcnt vmcnt(0)
+\ts_barrier
+.LBB0_1:
+\ts_mov_b32 m0, s4
+\ts_nop 0
+\tglobal_load_lds_dwordx4 v[0:1], off
+\ts_waitcnt vmcnt(1)
+\ts_barrier
+\tglobal_load_lds_dwordx4 v[0:1], off
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+.Lfunc_end0:
+''')
+    assert hazard_scan.scan_lds_dma(str(bad)) == 2                   # one DMA-BAR (1 in flight in the loop), one DMA-M0
+    good = tmp_path / 'good.s'
+    good.write_text(bad.read_text().replace('vmcnt(1)', 'vmcnt(0)').replace(
+        's_barrier\n\tglobal_load_lds_dwordx4 v[0:1], off\n\ts_cbranch', 's_barrier\n\ts_cbranch'))
+    assert hazard_scan.scan_lds_dma(str(good)) == 0

@@ -88,6 +88,111 @@ def scan(path):
             hist.append(dict(kind='other', dst=d, asm=False, ln=ln, waits=waits, trans=trans))
         if len(hist) > 4 * WINDOW: hist = hist[-2 * WINDOW:]
     return n_find
+# ---- LDS-DMA rings (round 4).  A kernel that fills LDS with global_load_lds_* and hands the data to OTHER waves through a
+# raw s_barrier is right only if, at every barrier, every piece of the unit about to be read has landed — and a wave can
+# only vouch for its OWN pieces, by an s_waitcnt vmcnt in front of ITS arrival at the barrier.  Checked on the generated
+# code, per kernel that contains an LDS-DMA instruction, by a forward dataflow over its control-flow graph:
+#   state   = upper bound of the vector-memory operations this wave may still have in flight (every VMEM instruction adds
+#             one — vmcnt counts them all —, s_waitcnt vmcnt(N) caps it at N; joins take the maximum; loops to a fixpoint)
+#   DMA-BAR   at an s_barrier the bound must be 0 — or, at the FIRST barrier of the kernel (the priming of a ring that keeps
+#             one unit ahead), at most `ahead` operations, all of them issued after the unit that is consumed first
+#   DMA-M0    global_load_lds_* takes its LDS base from M0: the s_mov_b32 m0 must be the last SALU write in front of it with
+#             at least one wait state (s_nop) between, and nothing else may write M0 in between
+VMEM = ('global_load', 'global_store', 'global_atomic', 'buffer_load', 'buffer_store', 'buffer_atomic', 'flat_load', 'flat_store',
+        'flat_atomic', 'scratch_load', 'scratch_store')
+def scan_lds_dma(path, ahead=5, verbose=False):
+    kernels, cur = {}, None
+    for ln, line in enumerate(open(path), 1):
+        s = line.strip()
+        head = s.split(';')[0].strip()
+        if head.endswith(':') and not head.startswith('.'):
+            cur = head[:-1]; kernels[cur] = []; continue
+        if cur is None or not s or s[0] == ';': continue
+        if s.startswith('.Lfunc_end'):
+            cur = None; continue                            # (blocks may follow the first s_endpgm: the function ends here)
+        if s.startswith('.L') and s.split(';')[0].strip().endswith(':'):
+            kernels[cur].append((ln, 'label', s.split(':')[0])); continue
+        if s[0] == '.': continue
+        body = s.split(';')[0].strip()
+        if not body: continue
+        kernels[cur].append((ln, 'ins', body))
+    n_find = 0
+    for kern, ins in kernels.items():
+        if not any(k == 'ins' and b.startswith('global_load_lds') for _, k, b in ins):
+            continue
+        # basic blocks
+        blocks, cur_b = [], {'labels': [], 'ins': []}
+        for ln, k, b in ins:
+            if k == 'label':
+                if cur_b['ins'] or cur_b['labels']:
+                    blocks.append(cur_b)
+                cur_b = {'labels': [b], 'ins': []}
+                continue
+            cur_b['ins'].append((ln, b))
+            op = b.split()[0]
+            if op.startswith(('s_cbranch', 's_branch', 's_endpgm', 's_setpc')):
+                blocks.append(cur_b); cur_b = {'labels': [], 'ins': []}
+        if cur_b['ins'] or cur_b['labels']: blocks.append(cur_b)
+        label_of = {}
+        for i, b in enumerate(blocks):
+            for l in b['labels']: label_of[l] = i
+        succ = []
+        for i, b in enumerate(blocks):
+            out = []
+            last = b['ins'][-1][1] if b['ins'] else ''
+            op = last.split()[0] if last else ''
+            tgt = last.split()[-1] if last else ''
+            if op.startswith('s_branch'): out = [label_of[tgt]]
+            elif op.startswith('s_cbranch'): out = [label_of[tgt]] + ([i + 1] if i + 1 < len(blocks) else [])
+            elif op.startswith(('s_endpgm', 's_setpc')): out = []
+            elif i + 1 < len(blocks): out = [i + 1]
+            succ.append(out)
+        CAP = 63
+        def transfer(state, b, report):
+            nonlocal n_find
+            o, first = state
+            m0_age = None          # instructions since the last s_mov_b32 m0 (None: M0 not set in this block yet)
+            for ln, body in b['ins']:
+                op = body.split()[0]
+                if op == 's_mov_b32' and body.split()[1].rstrip(',') == 'm0':
+                    m0_age = 0
+                elif op.startswith('global_load_lds'):
+                    if report and (m0_age is None or m0_age < 1):
+                        print(f'{kern}:{ln}: DMA-M0 {op} without s_mov_b32 m0 + a wait state directly in front'); n_find += 1
+                    o = min(o + 1, CAP)
+                    m0_age = None
+                elif op.startswith(VMEM):
+                    o = min(o + 1, CAP)
+                elif op == 's_waitcnt':
+                    m = re.search(r'vmcnt\((\d+)\)', body)
+                    if m: o = min(o, int(m.group(1)))
+                elif op == 's_barrier':
+                    allowed = ahead if first else 0
+                    if report and o > allowed:
+                        print(f'{kern}:{ln}: DMA-BAR s_barrier reached with up to {o} vector-memory operations of this wave in '
+                              f'flight (allowed {allowed}): another wave may read LDS-DMA data that has not landed'); n_find += 1
+                    if report and verbose: print(f'{kern}:{ln}: s_barrier, in flight <= {o} (first={first})')
+                    first = False
+                if m0_age is not None and not (op == 's_mov_b32' and body.split()[1].rstrip(',') == 'm0'):
+                    if op.startswith('s_') and not op.startswith('s_nop') and 'm0' in body.split(None, 1)[-1].split(',')[0]:
+                        m0_age = None      # M0 written by something else
+                    else:
+                        m0_age += 1
+            return (o, first)
+        IN = [None] * len(blocks)
+        IN[0] = (0, True)
+        work = [0]
+        while work:
+            i = work.pop()
+            out = transfer(IN[i], blocks[i], False)
+            for j in succ[i]:
+                new = out if IN[j] is None else (max(IN[j][0], out[0]), IN[j][1] and out[1])
+                if new != IN[j]:
+                    IN[j] = new; work.append(j)
+        for i, b in enumerate(blocks):
+            if IN[i] is not None: transfer(IN[i], b, True)
+    return n_find
 if __name__ == '__main__':
-    tot = sum(scan(p) for p in sys.argv[1:])
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    tot = sum(scan(p) for p in args) + sum(scan_lds_dma(p, verbose='--verbose' in sys.argv) for p in args)
     print('findings:', tot)
