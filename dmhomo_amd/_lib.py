@@ -132,6 +132,7 @@ SIGNATURES = {
     'dmh_sampler_seek': (c_int, [C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int,
                                  C.c_void_p]),
     'dmh_rng_indexed': (c_int, [c_f32p, c_int, c_i64, C.c_void_p, C.c_void_p, c_int, C.c_void_p]),
+    'dmh_rng_keep_mask': (c_int, [C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_float, C.c_void_p]),
     'dmh_rows_lincomb': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_i64, c_int, C.c_void_p]),
     'dmh_pixel_grid': (c_int, [c_f32p, c_int, c_int, c_int, c_float, C.c_void_p]),
     'dmh_norm_grid': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),

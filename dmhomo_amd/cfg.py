@@ -141,8 +141,19 @@ class Unet(nn.Module):
         if prob == 1:
             return None                                      # keep every row
         if prob == 0:
-            return torch.zeros((batch,), device=device, dtype=torch.uint8)
+            return self._null_mask(batch, device)
+        if type(self.rng) is DeviceRng and self.rng.keyed:           # draw + compare + uint8 in one launch
+            assert batch == self.rng.sample_ids.shape[0], (batch, self.rng.sample_ids.shape)
+            return ops.rng_keep_mask(self.rng.sample_ids, self.rng.state, prob)
         return (self.rng.uniform(batch, device) < prob).to(torch.uint8)
+
+    def _null_mask(self, batch, device):
+        """(batch,) uint8 zeros: every class dropped (the null pass, CFG:409) — allocated once, never written"""
+        z = self.__dict__.get('_null_keep')
+        if z is None or z.shape[0] != batch or z.device != torch.device(device):
+            z = torch.zeros((batch,), device=device, dtype=torch.uint8)
+            self.__dict__['_null_keep'] = z
+        return z
 
     def _stem(self, x, rgb_flow, mask):
         """cat((x, rgb_flow*mask)) -> NHWC -> init_conv: identical for the cond and the null pass (CFG:430-432)."""
@@ -154,7 +165,7 @@ class Unet(nn.Module):
                                  mask.to(torch.float32).contiguous(), reps=1, cpad=eng.cin_pad)
         return eng.stem(xin)
 
-    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None, x0=None, first=None):
+    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None, x0=None, first=None, out=None):
         """rows [rep*B + b]: sample b under class-keep mask keeps[rep] -> (len(keeps)*B, out_dim, H, W).
         first: engine.first_conv(x0) when the caller shares it between passes."""
         eng = self._engine
@@ -165,7 +176,7 @@ class Unet(nn.Module):
         time = time.to(torch.int64).contiguous()
         classes = classes.to(torch.int64).contiguous()
         cond = eng.embed(time, [(classes, k) for k in keeps], len(keeps))
-        return eng.trunk(x0, cond, taps, first=first)
+        return eng.trunk(x0, cond, taps, first=first, out=out)
 
     def forward(self, x, time, classes, rgb_flow, mask, cond_drop_prob=None):
         cond_drop_prob = default(cond_drop_prob, self.cond_drop_prob)
@@ -185,7 +196,7 @@ class Unet(nn.Module):
         """the two passes of CFG:404,409: (cond logits, null logits)."""
         B = x.shape[0]
         keep = self._keep_mask(B, self.cond_drop_prob, x.device)
-        null = torch.zeros((B,), device=x.device, dtype=torch.uint8)
+        null = self._null_mask(B, x.device)
         if self.cfg_mode == 'streams':
             nsub = max(1, min(int(self.stream_splits), B))       # row sub-batches per pass (each on its own stream)
             nstreams = 2 * nsub
@@ -208,8 +219,8 @@ class Unet(nn.Module):
                     with torch.cuda.stream(st):
                         kk = None if k is None else k[lo:hi].contiguous()
                         fs = None if first is None else (first[0][lo:hi], first[1][lo:hi])
-                        o = self._run(None, time[lo:hi], classes[lo:hi], None, None, [kk], x0=x0[lo:hi], first=fs)
-                        dst[lo:hi].copy_(o)
+                        # (the pass writes its rows of the result itself: the fused final projection's destination)
+                        self._run(None, time[lo:hi], classes[lo:hi], None, None, [kk], x0=x0[lo:hi], first=fs, out=dst[lo:hi])
             for st in self._side:
                 cur.wait_stream(st)
             return cond_out, null_out

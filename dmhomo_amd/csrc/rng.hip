@@ -84,7 +84,29 @@ __global__ __launch_bounds__(256) void rng_indexed_kernel(float* __restrict__ ou
   }
 }
 
+// the class-dropout mask of CFG:84-90 in one launch: keep[b] = uniform(seed, sample id, draw, element 0) < prob, as uint8 —
+// the value dmh_rng_indexed(kind 1) draws for the row, compared on the device (one block; B <= 65535)
+__global__ __launch_bounds__(256) void rng_keep_mask_kernel(unsigned char* __restrict__ keep, int B, const int64_t* __restrict__ ids,
+                                                            unsigned long long* state, float prob) {
+  const unsigned long long seed = state[0], draw = state[1];
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const unsigned long long sid = (unsigned long long)ids[b];
+    const U4 r = philox4x32_10(U4{0u, (uint32_t)draw, (uint32_t)sid, (uint32_t)(sid >> 32)}, (uint32_t)seed, (uint32_t)(seed >> 32));
+    keep[b] = ((float)(r.x >> 8) * 5.9604644775390625e-8f) < prob ? 1 : 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) state[1] = draw + 1;
+}
+
 }  // namespace
+
+extern "C" int dmh_rng_keep_mask(uint8_t* keep, int B, const int64_t* sample_ids, uint64_t* state, float prob, void* stream) {
+  DMH_REQUIRE(keep && sample_ids && state && B > 0 && B <= 65535, "dmh_rng_keep_mask: bad arguments");
+  hipLaunchKernelGGL(rng_keep_mask_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, keep, B, sample_ids,
+                     (unsigned long long*)state, prob);
+  DMH_CHECK_LAUNCH("dmh_rng_keep_mask");
+  return DMH_OK;
+}
 
 extern "C" int dmh_rng_indexed(float* out, int B, int64_t per_sample, const int64_t* sample_ids, uint64_t* state, int kind,
                                void* stream) {

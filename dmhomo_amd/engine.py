@@ -185,7 +185,7 @@ class UnetEngine:
         self.mlp_b = torch.cat(mlp_b).contiguous()
 
     # ------------------------------------------------------------------ blocks
-    def _res(self, r, x0, x1, ss_all, pixel_stats=False, pre=None, final=None, keep_out=True):
+    def _res(self, r, x0, x1, ss_all, pixel_stats=False, pre=None, final=None, keep_out=True, fin_out=None):
         """pixel_stats: return (x, stats) with the channel-LayerNorm statistics of x for the LinearAttention that
         follows (None where the block's last kernel cannot produce them).  pre: (y1, st1) = block1's convolution of x0
         and its GroupNorm partials, computed by the caller (``first_conv``).  final = (w, b): the block ends in its res_conv
@@ -201,7 +201,7 @@ class UnetEngine:
         y2, st2 = ops.conv2d(r.conv2, y1, in_coef=coef1, want_stats=True, in_bound=bound1)
         coef2 = ops.gn_finalize(st2, r.g2, r.b2, hw, self.groups)
         if final is not None:
-            return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, final=final, keep_out=keep_out)
+            return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, final=final, keep_out=keep_out, fin_out=fin_out)
         if r.res is not None:
             if pixel_stats and r.cout == 64 and r.res.k == 1 and 64 in ops.PIXEL_STATS_FUSABLE and ops.f16x3_default() \
                     and os.environ.get('DMH_CONV_PIXEL_STATS', '1') != '0':      # (knob: same-box A/Bs)
@@ -263,9 +263,10 @@ class UnetEngine:
         self.ensure_prepared()
         return ops.conv2d(self.downs[0][0].conv1, x0, None, want_stats=True)
 
-    def trunk(self, x0, cond, taps=None, first=None):
+    def trunk(self, x0, cond, taps=None, first=None, out=None):
         """everything after init_conv.  x0: stem() output with one row per row of ``cond``.
         first: ``first_conv(x0)`` when the caller has it already (shared between the CFG passes).
+        out: a contiguous (rows, out_dim, H, W) tensor that receives the result (a row slice of the caller's buffer).
         ``taps`` (dict) optionally receives the NHWC activation after each stage member, keyed like the
         reference's module names ('downs.0.0', 'mid_attn', ...): per-layer parity tests."""
         self.ensure_prepared()
@@ -302,8 +303,12 @@ class UnetEngine:
                 and ops.f16x3_default():
             # final_conv (CFG:341, 471-472) rides on the last block's res_conv launch: the block's output is projected
             # while it is still in registers, and only stored when a parity test taps it
-            x, y = self._res(fr, x, r, ss_all, final=(self.final_w, self.final_b), keep_out=taps is not None)
+            x, y = self._res(fr, x, r, ss_all, final=(self.final_w, self.final_b), keep_out=taps is not None, fin_out=out)
             tap('final_res_block', x)
             return y
         x = tap('final_res_block', self._res(fr, x, r, ss_all))
-        return ops.final_conv_nchw(x, self.final_w, self.final_b)
+        y = ops.final_conv_nchw(x, self.final_w, self.final_b)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y

@@ -121,12 +121,13 @@ CONV_LOG = None
 
 
 def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False, in_bound=None, final=None,
-           keep_out=True, pixel_stats=False, eps=1e-5):
+           keep_out=True, pixel_stats=False, eps=1e-5, fin_out=None):
     """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats).
     in_bound (B, k), with in_coef: upper bounds of the prologue's |a*x+b| per sample (gn_finalize(want_bound=True)).
     final = (w (n, Cout), b (n,) or None), 1x1 convs with Cout <= 64 only: also apply that pointwise projection to every
     finished output pixel and return (out, y) with y (B, n, H, W) NCHW — ``final_conv_nchw(out, w, b)`` without the second
     pass over ``out`` (DmhConv.fin_*); keep_out=False: ``out`` itself is not stored (returned as None).
+    fin_out: where y goes (a contiguous (B, n, H, W) tensor, e.g. a row slice of the caller's result) instead of a new tensor.
     pixel_stats (1x1 convs with Cout == 64): return (out, pstats) with pstats (B, H*W, 2) = the channel-LayerNorm (mean, rstd)
     of every output pixel, as ``dmh_pixel_stats(out)`` gives them, for ``linear_attention_fused(..., stats=)``."""
     B, H, W, c0 = src0.shape
@@ -136,11 +137,15 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
     ho, wo = conv_out_hw(pc, H, W)
     assert keep_out or final is not None
     out = _empty((B, ho, wo, pc.cout), src0) if keep_out else None
-    fin_w = fin_b = fin_out = None
+    fin_w = fin_b = None
     if final is not None:
         fin_w, fin_b = final
         assert fin_w.shape[1] == pc.cout and fin_w.is_contiguous() and not want_stats, (fin_w.shape, pc.cout)
-        fin_out = _empty((B, fin_w.shape[0], ho, wo), src0)
+        if fin_out is None:
+            fin_out = _empty((B, fin_w.shape[0], ho, wo), src0)
+        assert fin_out.shape == (B, fin_w.shape[0], ho, wo) and fin_out.is_contiguous() and fin_out.dtype == F32
+    else:
+        assert fin_out is None
     pst = None
     if pixel_stats:
         assert final is None and not want_stats and pc.cout == 64 and pc.k == 1, (pc.cout, pc.k)
@@ -407,6 +412,14 @@ def rng_indexed(shape, sample_ids, state, kind=0):
     assert sample_ids.shape == (B,) and state.shape == (4,) and state.dtype == torch.int64
     out = torch.empty(tuple(shape), device=sample_ids.device, dtype=F32)
     call('dmh_rng_indexed', ptr(out), B, out.numel() // B, ptr(sample_ids, torch.int64), ptr(state, torch.int64), int(kind))
+    return out
+
+
+def rng_keep_mask(sample_ids, state, prob):
+    """(B,) uint8: uniform draw of the indexed generator < prob (the class-dropout mask of CFG:84-90), one launch."""
+    B = sample_ids.shape[0]
+    out = torch.empty((B,), device=sample_ids.device, dtype=torch.uint8)
+    call('dmh_rng_keep_mask', ptr(out, torch.uint8), B, ptr(sample_ids, torch.int64), ptr(state, torch.int64), float(prob))
     return out
 
 

@@ -270,6 +270,10 @@ int dmh_sampler_seek(int32_t* cursor, int k, const DmhStep* table, const int64_t
 int dmh_rng_indexed(float* out, int B, int64_t per_sample, const int64_t* sample_ids, uint64_t* state, int kind,
                     void* stream);
 
+/* prob_mask_like CFG:84-90 on the indexed generator in one launch: keep[b] = (the kind-1 uniform of row b at the current
+ * draw) < prob, uint8; advances the draw index by one (it IS that draw) */
+int dmh_rng_keep_mask(uint8_t* keep, int B, const int64_t* sample_ids, uint64_t* state, float prob, void* stream);
+
 /* y = x*scale + shift elementwise (normalize / unnormalize, CFG:69-74) */
 int dmh_affine(const float* x, float* y, float scale, float shift, int64_t n, void* stream);
 /* in place on channels >= c0 of an NCHW tensor: x = x*scale + shift (flow channel remap, DDP:679,728) */

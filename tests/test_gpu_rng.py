@@ -161,3 +161,18 @@ def test_keyed_graph_equals_keyed_eager():
             outs.setdefault(graph, []).append(d.sample(c, rf01, flow, mk)[0].clone())
         assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][1], outs[False][0])
     m.cfg_mode = 'batched'
+
+
+def test_keep_mask_is_the_uniform_draw_compared_on_the_device():
+    """dmh_rng_keep_mask (the class-dropout mask of CFG:84-90 in one launch) == (dmh_rng_indexed kind 1 < prob) for the same
+    key and draw, and advances the draw index by one"""
+    from dmhomo_amd import ops
+    ids_h = list(range(500, 525)) + [2 ** 33 + 7]
+    ids = torch.tensor(ids_h, dtype=torch.int64, device=dev())
+    for prob in (0.5, 0.1, 0.9):
+        st = _state(1234, 9)
+        keep = ops.rng_keep_mask(ids, st, prob)
+        assert keep.dtype == torch.uint8 and st.cpu().tolist() == [1234, 10, 0, 0]
+        want = (ORNG.uniform(1234, ids_h, 9)[:, 0] < np.float32(prob)).astype(np.uint8)
+        assert np.array_equal(keep.cpu().numpy(), want)
+    assert 0 < int(ops.rng_keep_mask(torch.arange(4096, dtype=torch.int64, device=dev()), _state(5), 0.5).sum()) < 4096
