@@ -414,7 +414,7 @@ def roofline(log, args):
     canon_bytes = 4.0 * rows * args.image_size ** 2 * (64 + 64) + 4 * (9 * 64 * 64 + 3 * 64) + 8 * rows * 64
     canon_us = msc / max(nc, 1) * 1e3
     traffic, traffic_src = None, None
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         tpath = os.path.join(ROOT, 'profiles', name)
         if os.path.exists(tpath):       # FETCH_SIZE / WRITE_SIZE passes of rocprofv3 (tools/profile_round.sh)
             with open(tpath) as f:
