@@ -23,17 +23,31 @@ def init_from_env(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     use_cuda = torch.cuda.is_available()
     if use_cuda:
+        # DMH_SHARE_GPU=1 (tests on a one-GPU box): the ranks of the job time-share the visible GPUs; RCCL refuses two
+        # ranks on one device, so such a job runs over gloo (DMH_DIST_BACKEND=gloo; the collectives then stage through host memory)
+        if os.environ.get('DMH_SHARE_GPU') == '1':
+            local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
+    backend = backend or os.environ.get('DMH_DIST_BACKEND') or ('nccl' if use_cuda else 'gloo')
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(backend or ('nccl' if use_cuda else 'gloo'), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     device = torch.device('cuda', local) if use_cuda else torch.device('cpu')
     return rank, world, device
 
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def _host_staged():
+    """gloo moves device tensors only for broadcast / all_reduce: its scatter / gather / all_gather take host tensors"""
+    return dist.is_initialized() and dist.get_backend() == 'gloo'
+
+
+def _to_coll(t):
+    return t.cpu() if (_host_staged() and t.is_cuda) else t
 
 
 def shard_bounds(total, rank, world):
@@ -52,7 +66,7 @@ def broadcast_module_(module, src=0):
     world, rank = dist.get_world_size(), dist.get_rank()
     tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.is_floating_point()]
     others = [t for t in module.buffers() if not t.is_floating_point()]
-    flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+    flat = _to_coll(torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors]))
     n = flat.numel()
     per = (n + world - 1) // world
     padded = torch.zeros(per * world, device=flat.device, dtype=torch.float32)
@@ -65,7 +79,7 @@ def broadcast_module_(module, src=0):
     full = torch.cat(parts)[:n]
     off = 0
     for t in tensors:
-        t.copy_(full[off:off + t.numel()].reshape(t.shape).to(t.dtype))
+        t.copy_(full[off:off + t.numel()].reshape(t.shape).to(device=t.device, dtype=t.dtype))
         off += t.numel()
     for t in others:
         dist.broadcast(t, src=src)
@@ -159,6 +173,8 @@ def gather_records(imgs_u8, homos, dst=0):
     if world_size() == 1:
         return imgs_u8, homos
     world, rank = dist.get_world_size(), dist.get_rank()
+    dev_out = imgs_u8.device
+    imgs_u8, homos = _to_coll(imgs_u8), _to_coll(homos)
     nb = torch.tensor([imgs_u8.shape[0]], device=imgs_u8.device, dtype=torch.int64)
     sizes = [torch.empty_like(nb) for _ in range(world)]
     dist.all_gather(sizes, nb)
@@ -179,7 +195,8 @@ def gather_records(imgs_u8, homos, dst=0):
     dist.gather(ph, out_h, dst=dst)
     if rank != dst:
         return None, None
-    return (torch.cat([t[:n] for t, n in zip(out_i, sizes)]), torch.cat([t[:n] for t, n in zip(out_h, sizes)]))
+    return (torch.cat([t[:n] for t, n in zip(out_i, sizes)]).to(dev_out),
+            torch.cat([t[:n] for t, n in zip(out_h, sizes)]).to(dev_out))
 
 
 def noise_key(seed, total, rank, world, first_id=0):

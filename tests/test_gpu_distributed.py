@@ -61,3 +61,69 @@ def test_rccl_collectives_of_the_data_path_single_rank():
     r = subprocess.run([sys.executable, '-c', CHILD], capture_output=True, text=True, env=env, cwd=root, timeout=600)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0 and 'RCCL-OK' in r.stdout
+
+
+TWO_RANKS = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['DMH_ROOT'])
+from dmhomo_amd import cfg, ddpm, ops
+from dmhomo_amd import distributed as D
+rank, world, device = D.init_from_env()              # DMH_DIST_BACKEND=gloo, DMH_SHARE_GPU=1: both ranks on cuda:0
+assert world == 2 and device.type == 'cuda' and dist.get_backend() == 'gloo'
+S, total, steps = 128, 6, 4
+torch.manual_seed(100 + rank)                        # different weights per rank: rank 0's must win
+model = cfg.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+model.cfg_mode = 'streams'
+d = cfg.GaussianDiffusion(model, image_size=S, timesteps=1000, sampling_timesteps=steps, objective='pred_x0').to(device)
+D.broadcast_module_(d, src=0)
+d.hip_graph = True
+
+def run(lo, hi, ids):
+    conds = ddpm.SyntheticConditions(S, hi - lo, seed=1000 + lo, device=device)     # row i of the job: seed 1000 + i
+    data, classes = next(conds)
+    d.rng.key_by_sample(7, ids, device)
+    img, _, fl = d.sample(classes, data[:, -5:-2].contiguous(), data[:, -2:].contiguous(), data[:, -6:-5].contiguous())
+    return ops.to_uint8(img), ops.dlt_homography(fl)
+
+lo, hi = D.shard_bounds(total, rank, world)
+ids = D.key_noise_by_sample(d, 7, total, device=device)
+assert list(ids) == list(range(lo, hi))
+u8, hm = run(lo, hi, ids)
+gi, gh = D.gather_records(u8, hm, dst=0)
+t = torch.tensor([float(rank + 1)], device=device, dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+assert t.item() == 2.0
+if rank == 0:
+    assert gi.shape == (total, 6, S, S) and gh.shape == (total, 3, 3)
+    wi, wh = run(0, total, range(total))             # the same job in ONE process
+    assert torch.equal(gi, wi), int((gi != wi).sum())
+    assert torch.equal(gh, wh)
+    assert not torch.equal(gi[0], gi[3])
+    print('TWO-RANKS-OK')
+else:
+    assert gi is None and gh is None
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_ranks_shard_a_job_and_reproduce_the_single_process_records(tmp_path):
+    """BASELINE configs[2]'s data path with more than one rank on real hardware, as far as a one-GPU box allows: two
+    processes (torch.distributed.run) time-share the GPU and talk over gloo (RCCL refuses two ranks on one device) — weights
+    of rank 0 reach rank 1 (scatter + all-gather payload), each rank samples its shard of a 6-sample job at the real geometry
+    (dim 64, 128x128, 'streams', per-step HIP graph, noise keyed by global sample index), the uint8 records and homographies
+    are gathered in rank order — and rank 0 checks them BITWISE against the same job run in one process."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / 'two_ranks.py'
+    script.write_text(TWO_RANKS)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(DMH_ROOT=root, DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+                        '127.0.0.1', '--master-port', str(port), str(script)], capture_output=True, text=True, env=env, cwd=root,
+                       timeout=900)
+    print(r.stdout[-2000:], r.stderr[-3000:])
+    assert r.returncode == 0 and 'TWO-RANKS-OK' in r.stdout
