@@ -278,7 +278,7 @@ def main():
     # ---- synthetic conditions of this rank's shard, resident in HBM
     lo, hi = D.shard_bounds(args.bs * world, rank, world)
     # noise keyed by GLOBAL sample index (dmh_rng_indexed inside the captured denoise step): row i of the N-rank job is
-    # row i of the 1-GPU job, whatever N is (the reference's N hand-started processes all draw the same default stream)
+    # row i of the 1-GPU job, whatever N is (the reference's N hand-started processes each draw their own, unseeded stream)
     D.key_noise_by_sample(diffusion, 99, args.bs * world, device=device)
     conds = ddpm.SyntheticConditions(args.image_size, hi - lo, seed=1000 + lo, device=device)
     data, classes = next(conds)

@@ -210,8 +210,9 @@ def noise_key(seed, total, rank, world, first_id=0):
 
 def key_noise_by_sample(diffusion, seed, total, first_id=0, device=None):
     """key ``diffusion.rng`` for this process's shard of a global batch of ``total`` samples (rank / world from the process
-    group; one process: the whole batch).  Replaces the reference's per-process stream generator (CFG:679,705,90; N
-    hand-started processes of DGM/dgm_sample.py:13-18 all start from the same default seed)."""
+    group; one process: the whole batch).  Replaces the reference's per-process stream generator (CFG:679,705,90; the N
+    hand-started processes of DGM/dgm_sample.py:13-18 each draw from torch's default generator, seeded at random per process:
+    row b of a draw depends on the shard and nothing is reproducible)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     seed, ids = noise_key(seed, total, rank, world, first_id)
     diffusion.rng.key_by_sample(seed, ids, device)

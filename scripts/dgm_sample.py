@@ -49,6 +49,7 @@ num_classes = 1
 
 def main():
     rank, world, device = D.init_from_env()
+    torch.manual_seed(args.seed)         # (the initialisation used when no checkpoint is found; torch seeds its CPU generator at random)
     model = Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=6, num_classes=num_classes).to(device)
     model.cfg_mode = 'streams'
     diffusion = GaussianDiffusion(model, image_size=args.image_size, timesteps=1000, sampling_timesteps=args.s_step,
@@ -57,7 +58,8 @@ def main():
     trainer = Trainer(diffusion, folder, train_batch_size=args.bs, train_lr=1e-4, train_num_steps=200000,
                       gradient_accumulate_every=2, ema_decay=0.995, amp=False, results_folder='results',
                       save_and_sample_every=2000, num_samples=4, augment_horizontal_flip=False, num_worker=0,
-                      total_data_slice_idx=args.gpu_nums, data_slice_idx=args.i, shuffle=False)
+                      total_data_slice_idx=args.gpu_nums, data_slice_idx=args.i, shuffle=False,
+                      split_batches=False)     # --bs is PER PROCESS, as for the reference's hand-started processes (SAMPLE:13-18)
     # rank 0 alone reads the checkpoint; the online and the EMA copy reach the other ranks as one RCCL payload each
     have = os.path.exists(os.path.join('results', f'model-{args.c}.pt')) if rank == 0 else None
     if not D.load_on_rank0_and_broadcast(trainer, args.c if have else None):
@@ -71,8 +73,8 @@ def main():
     train_list, part = [], args.part
     for b in range(args.batches):
         # noise keyed by (seed, GLOBAL sample index): rank r of N draws rows [b*bs*N + r*bs, +bs) of the job's noise, so
-        # the records do not depend on how many processes made them (the reference's N hand-started processes all start
-        # from the same default generator state, SAMPLE:13-18: every process draws the SAME noise)
+        # the noise of a sample does not depend on how many processes made the job (the reference's N hand-started
+        # processes, SAMPLE:13-18, each draw from their own default generator: torch seeds it at random per process)
         D.key_noise_by_sample(sampler, args.seed, args.bs * world, first_id=b * args.bs * world, device=device)
         ret = trainer.sample(args.i, device, step=len(train_list))
         train_list.append(ret)

@@ -127,3 +127,52 @@ def test_two_ranks_shard_a_job_and_reproduce_the_single_process_records(tmp_path
                        timeout=900)
     print(r.stdout[-2000:], r.stderr[-3000:])
     assert r.returncode == 0 and 'TWO-RANKS-OK' in r.stdout
+
+
+@pytest.mark.parametrize('ranks', [1, 2])
+def test_dgm_sample_script_end_to_end(tmp_path, ranks):
+    """scripts/dgm_sample.py (the counterpart of DGM/dgm_sample.py: same flags, same record files) as a user starts it —
+    one process, and two processes under torch.distributed.run (time-sharing the GPU over gloo on this one-GPU box): rank 0
+    alone would read the checkpoint (none here: the seeded initialisation is broadcast), every rank writes its part file in the
+    reference's list-of-dict format, the records are uint8 (bs, 6, S, S) + float64 (bs, 3, 3), and — noise being keyed by the
+    global sample index — the two ranks' records differ from each other while a repeated run reproduces them bit for bit."""
+    import socket
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, 'scripts', 'dgm_sample.py')
+    args = ['-c', 'absent', '--s_step', '3', '--bs', '3', '--exp', 'run0', '--image_size', '128', '--batches', '2', '--seed', '5']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4', PYTHONPATH=root)
+
+    def run(workdir):
+        os.makedirs(workdir)
+        if ranks == 1:
+            cmd = [sys.executable, script] + args
+            e = env
+        else:
+            with socket.socket() as sk:
+                sk.bind(('127.0.0.1', 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ranks}', '--master-addr',
+                   '127.0.0.1', '--master-port', str(port), script] + args
+            e = dict(env, DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1')
+        r = subprocess.run(cmd, capture_output=True, text=True, env=e, cwd=workdir, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        out = {}
+        for rk in range(ranks):
+            f = os.path.join(workdir, 'traindata', 'run0', 'dataset', f'idx_0_rank_{rk}_part_0_dm_cahomo_0.006k.npy')
+            assert os.path.exists(f), os.listdir(os.path.join(workdir, 'traindata', 'run0', 'dataset'))
+            recs = np.load(f, allow_pickle=True)
+            assert len(recs) == 2
+            for rec in recs:
+                assert rec['imgs'].dtype == np.uint8 and rec['imgs'].shape == (3, 6, 128, 128)
+                assert rec['homos'].dtype == np.float64 and rec['homos'].shape == (3, 3, 3)
+            out[rk] = recs
+        return out
+    a, b = run(str(tmp_path / 'a')), run(str(tmp_path / 'b'))
+    for rk in range(ranks):
+        for x, y in zip(a[rk], b[rk]):
+            assert np.array_equal(x['imgs'], y['imgs']) and np.array_equal(x['homos'], y['homos'])
+    assert not np.array_equal(a[0][0]['imgs'], a[0][1]['imgs'])               # the second batch draws new noise
+    if ranks == 2:
+        assert not np.array_equal(a[0][0]['imgs'], a[1][0]['imgs'])
