@@ -348,7 +348,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'ms_per_denoise_step': elapsed / args.steps / args.s_step * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'rccl_ranks': rccl_ranks,
+            'rccl_ranks': rccl_ranks, 'backend': (dist.get_backend() if world > 1 else None),
             'config': {'workload': f'DGM CFG-Unet dim={args.dim} {args.image_size}x{args.image_size} '
                                    f'bs={args.bs}/GPU s_step={args.s_step} cond_scale=3 ' + (
                                        '(BASELINE configs[1])' if (args.dim, args.image_size, args.bs, args.s_step) ==

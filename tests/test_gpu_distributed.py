@@ -176,3 +176,23 @@ def test_dgm_sample_script_end_to_end(tmp_path, ranks):
     assert not np.array_equal(a[0][0]['imgs'], a[0][1]['imgs'])               # the second batch draws new noise
     if ranks == 2:
         assert not np.array_equal(a[0][0]['imgs'], a[1][0]['imgs'])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on real hardware — the launcher starts two ranks, the weight payload travels, each
+    rank samples its shard (per-step graph, keyed noise), records are gathered every step, the time is the maximum over
+    ranks, rank 0 prints ONE line — with the two ranks time-sharing the box's one GPU over gloo (the driver's 8-GPU run is the
+    same code over RCCL)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--bs', '4', '--s_step', '4', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-roofline'], capture_output=True, text=True, env=env, cwd=root,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['backend'] == 'gloo' and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == 8 and d['value'] > 0 and d['steps'] == 2
