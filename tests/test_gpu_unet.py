@@ -135,6 +135,37 @@ def test_unet_cfg_ragged_sizes_vs_oracle(size, B):
     close_rel(f'cfg ragged {size} out', out.cpu(), ref, OUT_REL)
 
 
+@pytest.mark.parametrize('kw', [
+    dict(dim=16, dim_mults=(1, 2), channels=3, num_classes=4, resnet_block_groups=4),
+    dict(dim=16, dim_mults=(1, 2, 4, 8), channels=6, num_classes=2, out_dim=5),
+    dict(dim=24, dim_mults=(1, 3), channels=6, num_classes=1, resnet_block_groups=2),
+    dict(dim=8, dim_mults=(1,), channels=6, num_classes=1),
+    dict(dim=16, dim_mults=(1, 2), channels=6, num_classes=1, learned_variance=True),
+], ids=lambda kw: ','.join(f'{k}={v}' for k, v in kw.items() if k != 'dim_mults') + f",mults={len(kw['dim_mults'])}")
+def test_unet_cfg_constructor_variants_vs_oracle(kw):
+    """the constructor arguments of CFG:304-318 away from the DGM's values: other widths / depths (one to four stages, a
+    non-power-of-two multiplier), 3 image channels, several classes with a mixed keep mask, 2 or 4 GroupNorm groups, an
+    explicit out_dim, learned_variance (out_dim = 2 * channels) — forward against the oracle"""
+    from dmhomo_amd import cfg
+    m = cfg.Unet(**kw)
+    sd = det_state_dict(shapes_of(m), 5)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    B, S = 2, 32
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, kw['channels'], S, S, generator=gen)
+    rf = torch.rand(B, 3, S, S, generator=gen) * 2 - 1
+    mk = (torch.rand(B, 1, S, S, generator=gen) > 0.4).float()
+    t, c = torch.tensor([700, 20]), torch.randint(0, kw['num_classes'], (B,), generator=gen)
+    keep = torch.tensor([True, False])
+    with torch.no_grad():
+        ref = OU.cfg_unet_forward(sd, x, t, c, rf, mk, keep, groups=kw.get('resnet_block_groups', 8))
+    m.rng = ReplayDeviceRng([torch.where(keep, 0.25, 0.75)])
+    out = m(g(x), g(t), g(c), g(rf), g(mk))
+    assert out.shape == ref.shape
+    close_rel(f'CFG Unet {kw}', out, ref, OUT_REL)
+
+
 def test_unet_rows_are_independent():
     """size-independent property: each output row depends on its own sample only (bitwise) — what makes
     sample-sharding across GPUs exact"""
