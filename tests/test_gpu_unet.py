@@ -340,6 +340,53 @@ def test_ddim_trace_s32_vs_golden(golden_dir, S):
     close(f'ddim S=32 {S}x{S} img', img.cpu(), T(gd[f's{S}.img']), rtol=0, atol=4e-4)
 
 
+@pytest.mark.parametrize('kw', [dict(eta=0.0), dict(eta=0.5), dict(schedule='linear'), dict(T=200, S=7), dict(cond_scale=1.0),
+                                dict(cond_scale=0.5), dict(cond_scale=7.0), dict(drop=0.0), dict(drop=1.0), dict(drop=0.2),
+                                dict(objective='pred_v', eta=0.3, schedule='linear'), dict(S=1), dict(T=50, S=49)],
+                         ids=lambda kw: ','.join(f'{k}={v}' for k, v in kw.items()))
+def test_sampler_argument_variants_vs_oracle(kw):
+    """GaussianDiffusion / Unet arguments away from the DGM's values — ddim_sampling_eta 0 / 0.5, the linear schedule, other
+    (T, S) incl. S = 1 and S = T - 1, cond_scale 1 (no guidance: one pass, one draw fewer per step) / 0.5 / 7, cond_drop_prob
+    0 / 1 (no draw) / 0.2, pred_v — the sampler against the oracle on replayed draws (the number of draws consumed must
+    match too), and the per-step graph against the eager loop, bitwise.  T = 100 by default: at T = 1000 a 5-step schedule's
+    first jump is fp32 cancellation noise in the reference itself (deviations)."""
+    from dmhomo_amd import cfg
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    T, S = kw.get('T', 100), kw.get('S', 5)
+    m = cfg.Unet(dim=8, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1, cond_drop_prob=kw.get('drop', 0.5))
+    sd = det_state_dict(shapes_of(m), 0)
+    m.load_state_dict(sd)
+    m = m.to(dev())
+    obj, sched, eta, cs = kw.get('objective', 'pred_x0'), kw.get('schedule', 'cosine'), kw.get('eta', 1.), kw.get('cond_scale', 3.)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=T, sampling_timesteps=S, objective=obj, beta_schedule=sched,
+                              ddim_sampling_eta=eta).to(dev())
+    B = 2
+    gen = torch.Generator().manual_seed(9)
+    rf01 = torch.rand(B, 3, 16, 16, generator=gen)
+    mk = (torch.rand(B, 1, 16, 16, generator=gen) > 0.4).float()
+    fl = torch.randn(B, 2, 16, 16, generator=gen)
+    c = torch.zeros(B, dtype=torch.long)
+    torch.manual_seed(4)
+    rec = OD.RecordRng()
+    with torch.no_grad():
+        ref, _, _ = OD.cfg_sample(sd, OD.schedule_buffers(T, sched), c, rf01, fl, mk, image_size=16, channels=6,
+                                  sampling_timesteps=S, objective=obj, cond_scale=cs, cond_drop_prob=kw.get('drop', 0.5), eta=eta,
+                                  rng=rec)
+    assert torch.isfinite(ref).all()
+    d.rng = ReplayDeviceRng(rec.draws)
+    img, _, _ = d.sample(g(c), g(rf01), g(fl), g(mk), cond_scale=cs)
+    assert d.rng.i == len(rec.draws)                      # the same number of draws, in the same order
+    close(f'sampler {kw}', img.cpu(), ref, rtol=0, atol=4e-4)
+    from dmhomo_amd.cfg import DeviceRng
+    d.rng = DeviceRng()
+    outs = []
+    for graph in (False, True):
+        d.hip_graph = graph
+        torch.manual_seed(11)
+        outs.append(d.sample(g(c), g(rf01), g(fl), g(mk), cond_scale=cs)[0].clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def _fullsize_s32_inputs(B):
     _, rf, mk = _cond_inputs(B, 128, 700)
     return (rf + 1) / 2, rand((B, 2, 128, 128), 703), mk, torch.zeros(B, dtype=torch.long)
