@@ -87,3 +87,43 @@ def test_dlt_homography_and_save_train_pair(gd):
     ha = ddpm.homo_gen(fa.to(dev())).cpu().numpy()[:, 0]
     np.testing.assert_allclose(ha, gd['a.H1'], rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(ha, OG.homo_gen_normal_eq(fa).numpy()[:, 0], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_flow_warp_fuzz_bit_exact(seed):
+    """random shapes (odd sizes, 1-6 channels, batch 1-3) and flows from sub-pixel to several image widths, incl. exact
+    integers, exact halves and the image border: corner indices and the warped image bit-exact against the oracle (torch's CPU
+    grid_sample, align_corners=True, border padding — what the reference's flow_warp calls, DDP:1262-1280)"""
+    from dmhomo_amd import ops
+    import random
+    rnd = random.Random(seed)
+    gen = torch.Generator().manual_seed(1000 + seed)
+    B, C = rnd.randint(1, 3), rnd.choice([1, 2, 3, 6])
+    H, W = rnd.randint(2, 70), rnd.randint(2, 70)
+    img = torch.randn(B, C, H, W, generator=gen)
+    mag = rnd.choice([0.4, 3.0, 40.0, 300.0])
+    flow = (torch.rand(B, 2, H, W, generator=gen) * 2 - 1) * mag
+    sel = torch.rand(B, 2, H, W, generator=gen)
+    flow = torch.where(sel < 0.15, flow.round(), flow)                          # integer displacements
+    flow = torch.where((sel >= 0.15) & (sel < 0.25), flow.round() + 0.5, flow)  # exact halves
+    flow[:, :, 0, :] = -1.0                                                      # rows that leave through the top border
+    out, x0, y0 = ops.flow_warp(img.to(dev()), flow.to(dev()), want_indices=True)
+    ix, iy, rx0, ry0 = OG.warp_coords(flow)
+    assert torch.equal(x0.cpu(), rx0) and torch.equal(y0.cpu(), ry0)
+    assert torch.equal(out.cpu(), OG.flow_warp(img, flow))
+
+
+def test_dlt_recovers_homographies_of_any_strength():
+    """flow of a known homography -> dmh_dlt_homography -> the homography (f64, normal equations): identity (zero flow), pure
+    translation, strong perspective; and the batched records of saveTrainPair"""
+    from dmhomo_amd import ddpm
+    Hs = np.stack([np.eye(3),
+                   np.array([[1, 0, 7.5], [0, 1, -3.25], [0, 0, 1.]]),
+                   np.array([[1.05, .02, 2.], [-.03, .97, 1.], [4e-4, -3e-4, 1.]]),
+                   np.array([[.9, .1, -4.], [.05, 1.1, 6.], [-6e-4, 5e-4, 1.]])])
+    for S in (32, 128):
+        flow, _ = ddpm.homo_to_flow_rgb(Hs, S, S)
+        got = ddpm.homo_gen(flow).reshape(-1, 3, 3).cpu().numpy()
+        err = np.abs(got - Hs).max()
+        print(f'[parity] DLT round trip at {S}x{S}: max |H - H_true| = {err:.2e}')
+        assert err < 8e-5        # measured 7.5e-6: the flow is fp32 (1e-7 relative on coordinates up to 128) and w' carries the reference's + 1e-6
