@@ -115,8 +115,11 @@ extern "C" int dmh_rng_indexed(float* out, int B, int64_t per_sample, const int6
   DMH_REQUIRE(B <= 65535, "dmh_rng_indexed: B=%d (limit 65535 rows per launch)", B);
   DMH_REQUIRE(per_sample < ((int64_t)1 << 34), "dmh_rng_indexed: %lld elements per sample (limit 2^34)", (long long)per_sample);
   const int64_t nq = (per_sample + 3) >> 2;
+  // every workgroup ends with a returning atomic on ONE word (the arrival ticket): at 2400 workgroups those tickets were most
+  // of the launch (33 us for 2.4 M normals).  About two workgroups per CU in total, each looping over its share
   int64_t gx = cdiv64(nq, 256);
-  gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+  const int64_t cap = B >= 512 ? 1 : 512 / B;
+  gx = gx < 1 ? 1 : (gx > cap ? cap : gx);
   hipLaunchKernelGGL(rng_indexed_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, (hipStream_t)stream, out, per_sample,
                      sample_ids, (unsigned long long*)state, kind);
   DMH_CHECK_LAUNCH("dmh_rng_indexed");

@@ -1,0 +1,15 @@
+"""time of one noise draw of the headline step (25 x 6 x 128 x 128 normals) and of the class-dropout mask"""
+import sys, torch
+sys.path.insert(0, '/root/repo')
+from dmhomo_amd import ops
+dev = torch.device('cuda', 0)
+ids = torch.arange(25, dtype=torch.int64, device=dev)
+st = torch.tensor([7, 0, 0, 0], dtype=torch.int64, device=dev)
+for _ in range(5):
+    ops.rng_indexed((25, 6, 128, 128), ids, st, 0)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); e0.record()
+for _ in range(200):
+    ops.rng_indexed((25, 6, 128, 128), ids, st, 0)
+e1.record(); torch.cuda.synchronize()
+print('rng_indexed normals 25x6x128x128: %.1f us per launch' % (e0.elapsed_time(e1) * 1e3 / 200))
