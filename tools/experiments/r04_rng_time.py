@@ -13,3 +13,11 @@ for _ in range(200):
     ops.rng_indexed((25, 6, 128, 128), ids, st, 0)
 e1.record(); torch.cuda.synchronize()
 print('rng_indexed normals 25x6x128x128: %.1f us per launch' % (e0.elapsed_time(e1) * 1e3 / 200))
+x = torch.randn(25, 6, 128, 128, device=dev); rf = torch.randn(25, 3, 128, 128, device=dev); mk = torch.rand(25, 1, 128, 128, device=dev)
+for _ in range(5):
+    ops.assemble_input(x, rf, mk, reps=1, cpad=12)
+torch.cuda.synchronize(); e0.record()
+for _ in range(200):
+    ops.assemble_input(x, rf, mk, reps=1, cpad=12)
+e1.record(); torch.cuda.synchronize()
+print('assemble_input 25 rows 128x128 -> 12 channels NHWC: %.1f us per launch' % (e0.elapsed_time(e1) * 1e3 / 200))
