@@ -105,6 +105,10 @@ class DeviceRng:
         return torch.zeros((n,), device=device).float().uniform_(0, 1)
 
 
+# development knob (same-box A/Bs): '0' = the replayed step computes its embeddings and (scale, shift) rows per step
+SS_TABLES = __import__('os').environ.get('DMH_SS_TABLES', '1') != '0'
+
+
 class Unet(nn.Module):
     """CFG:302-466.  ``forward`` launches the HIP program; parameters live in holders."""
 
@@ -175,6 +179,17 @@ class Unet(nn.Module):
             x0 = x0.repeat(len(keeps), 1, 1, 1)              # row copies of the shared stem output
         time = time.to(torch.int64).contiguous()
         classes = classes.to(torch.int64).contiguous()
+        tab = self.__dict__.get('_ss_tab')
+        if tab is not None:
+            # a replayed denoise step (GaussianDiffusion._sample_graphed): the (scale, shift) rows of every ResnetBlock come
+            # from tables indexed by the step cursor and the row's class / keep bit — one small launch per pass instead of the
+            # two embeddings, four small linears and the 512 -> 8 k linear at its head; bitwise the same rows (UnetEngine.ss_tables)
+            T, Ct, cursor = tab
+            B = classes.shape[0]
+            ss_all = torch.empty((len(keeps) * B, T.shape[1]), device=T.device, dtype=torch.float32)
+            for r, k in enumerate(keeps):
+                ops.ss_gather(T, Ct, eng.mlp_b, cursor, classes, k, out=ss_all[r * B:(r + 1) * B])
+            return eng.trunk(x0, None, taps, first=first, out=out, ss_all=ss_all)
         cond = eng.embed(time, [(classes, k) for k in keeps], len(keeps))
         return eng.trunk(x0, cond, taps, first=first, out=out)
 
@@ -537,6 +552,11 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                   'rf': torch.empty_like(ins[1]), 'img': torch.zeros(shape, device=device),
                   'tcond': torch.zeros((shape[0],), device=device, dtype=torch.long)}
 
+            # the embedding side of the network depends on (step, class, keep bit) only: tables, made once per capture
+            if SS_TABLES:
+                T_tab, C_tab = eng.ss_tables(times)
+                st['ss_tab'] = (T_tab, C_tab, cursor)
+
             def mid():                                       # one denoise step of CFG:684-707, in place on st['img']
                 cond, null = self._network(st['img'], st['tcond'], ins[0], st['rf'], ins[2], cond_scale)
                 noise = self.rng.randn(shape, device).contiguous()
@@ -555,17 +575,21 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
             ops.sampler_seek(cursor, 0, table, tt, cur, st['tcond'])
             side = torch.cuda.Stream(device=device)
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                mid()
-                ops.sampler_seek(cursor, len(steps) - 1, table, tt, cur, st['tcond'])   # last() runs on the last entry
-                last()
-            torch.cuda.current_stream().wait_stream(side)
-            g_mid = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_mid, capture_error_mode='thread_local'):
-                mid()
-            g_last = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_last, pool=g_mid.pool(), capture_error_mode='thread_local'):
-                st['out'] = last()
+            self.model.__dict__['_ss_tab'] = st.get('ss_tab')         # (read by Unet._run while the step bodies run)
+            try:
+                with torch.cuda.stream(side):
+                    mid()
+                    ops.sampler_seek(cursor, len(steps) - 1, table, tt, cur, st['tcond'])   # last() runs on the last entry
+                    last()
+                torch.cuda.current_stream().wait_stream(side)
+                g_mid = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_mid, capture_error_mode='thread_local'):
+                    mid()
+                g_last = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_last, pool=g_mid.pool(), capture_error_mode='thread_local'):
+                    st['out'] = last()
+            finally:
+                self.model.__dict__.pop('_ss_tab', None)
             self.rng.restore(rng_state, device)
             st['graph'], st['graph_last'] = g_mid, g_last
             self.__dict__['_graph_state'] = st

@@ -76,6 +76,37 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
   }
 }
 
+// (scale, shift) rows of a replayed denoise step from tables: the linear over the concatenated ResnetBlock mlps is
+// v = (q0 + q1) + (q2 + q3) + bias with q0, q1 the partial sums over the TIME half of its input and q2, q3 those over the CLASS
+// half (linear_kernel, in_dim = 512 in four quarters) — the first pair depends on the timestep only, the second on (class, kept
+// or dropped) only.  T[s] = q0 + q1 of denoise step s and C[c] = q2 + q3 of class c (row ncls: the null embedding) are made once
+// per weight version and schedule by linear_kernel itself (the other half of its input zeroed: SiLU(0) = 0 adds exact zeros),
+// and a step's rows are  out[b] = (T[*cursor] + C[keep[b] ? classes[b] : ncls]) + bias  — bitwise what the six launches at the
+// head of a pass (two embeddings, four small linears, the 512 -> 8 k linear: ~87 us alone on the chip) compute.
+__global__ __launch_bounds__(256) void ss_gather_kernel(const float* __restrict__ T, const float* __restrict__ Ct,
+                                                        const float* __restrict__ bias, const int32_t* __restrict__ cursor,
+                                                        const int64_t* __restrict__ classes, const unsigned char* __restrict__ keep,
+                                                        int ncls, float* __restrict__ out, int N) {
+  const int b = blockIdx.y;
+  const int o4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (o4 >= N) return;
+  const int step = *cursor;
+  const bool kept = keep ? keep[b] != 0 : true;
+  const int row = kept ? (int)classes[b] : ncls;
+  const float4 t = ld4(T + (size_t)step * N + o4), c = ld4(Ct + (size_t)row * N + o4), bb = ld4(bias + o4);
+  st4(out + (size_t)b * N + o4, make_float4((t.x + c.x) + bb.x, (t.y + c.y) + bb.y, (t.z + c.z) + bb.z, (t.w + c.w) + bb.w));
+}
+
+extern "C" int dmh_ss_gather(const float* T, const float* C, const float* bias, const int32_t* cursor, const int64_t* classes,
+                             const uint8_t* keep, int ncls, float* out, int B, int N, void* stream) {
+  DMH_REQUIRE(T && C && bias && cursor && classes && out && B > 0 && N > 0 && N % 4 == 0 && ncls > 0 && B <= 65535,
+              "dmh_ss_gather: bad arguments");
+  hipLaunchKernelGGL(ss_gather_kernel, dim3(cdiv(N / 4, 256), B), dim3(256), 0, (hipStream_t)stream, T, C, bias, cursor, classes,
+                     keep, ncls, out, N);
+  DMH_CHECK_LAUNCH("dmh_ss_gather");
+  return DMH_OK;
+}
+
 extern "C" int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* out, int R, int dim, void* stream) {
   DMH_REQUIRE(t && freq && out && R > 0 && dim > 0 && dim % 2 == 0, "dmh_sinusoidal_embed: bad arguments");
   const int total = R * (dim / 2);

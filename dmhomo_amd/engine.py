@@ -250,6 +250,28 @@ class UnetEngine:
                 ops.linear(cm, self.c_w2, self.c_b2, out=cond[r * B:(r + 1) * B, td:])
         return cond
 
+    def ss_tables(self, times):
+        """tables for ``ops.ss_gather`` (a replayed sampling loop): T (S, N) = the time half's contribution to the (scale, shift)
+        linear for every timestep of ``times``, C (num_classes + 1, N) = the class half's for every class and (last row) the
+        null embedding — each made by the SAME launches the per-step path uses (``embed``, then the linear over the
+        concatenated mlp weight without its bias) on embedding rows whose other half is zero, so that (T + C) + bias is bit for
+        bit the per-step result (the linear adds its input quarters as (q0 + q1) + (q2 + q3): time | class)."""
+        self.ensure_prepared()
+        assert self.has_classes and self.emb_dim == 2 * self.t_w2.shape[1] and self.emb_dim % 4 == 0
+        dev, td = self.mlp_wt.device, self.t_w2.shape[1]
+        t = torch.as_tensor(list(times), dtype=torch.int64).to(dev)
+        ncls = self.c_table.shape[0]
+        cls = torch.arange(ncls + 1, dtype=torch.int64, device=dev).clamp(max=ncls - 1)
+        keep = torch.ones((ncls + 1,), dtype=torch.uint8, device=dev)
+        keep[ncls] = 0
+        cond_t = self.embed(t, [(torch.zeros_like(t), None)], 1)
+        cond_t[:, td:].zero_()
+        cond_c = self.embed(torch.zeros((ncls + 1,), dtype=torch.int64, device=dev), [(cls, keep)], 1)
+        cond_c[:, :td].zero_()
+        T = ops.linear(cond_t, self.mlp_wt, None, act_in='silu')
+        Ct = ops.linear(cond_c, self.mlp_wt, None, act_in='silu')
+        return T, Ct
+
     def stem(self, xin):
         """init_conv (CFG:432) on the assembled NHWC input; its output is shared by every CFG pass."""
         self.ensure_prepared()
@@ -263,10 +285,11 @@ class UnetEngine:
         self.ensure_prepared()
         return ops.conv2d(self.downs[0][0].conv1, x0, None, want_stats=True)
 
-    def trunk(self, x0, cond, taps=None, first=None, out=None):
+    def trunk(self, x0, cond, taps=None, first=None, out=None, ss_all=None):
         """everything after init_conv.  x0: stem() output with one row per row of ``cond``.
         first: ``first_conv(x0)`` when the caller has it already (shared between the CFG passes).
         out: a contiguous (rows, out_dim, H, W) tensor that receives the result (a row slice of the caller's buffer).
+        ss_all: the (scale, shift) rows when the caller has them already (``ss_tables`` + ``ops.ss_gather``); ``cond`` is then unused.
         ``taps`` (dict) optionally receives the NHWC activation after each stage member, keyed like the
         reference's module names ('downs.0.0', 'mid_attn', ...): per-layer parity tests."""
         self.ensure_prepared()
@@ -275,7 +298,8 @@ class UnetEngine:
             if taps is not None:
                 taps[name] = v
             return v
-        ss_all = ops.linear(cond, self.mlp_wt, self.mlp_b, act_in='silu')
+        if ss_all is None:
+            ss_all = ops.linear(cond, self.mlp_wt, self.mlp_b, act_in='silu')
         x = tap('init_conv', x0)
         r = x
         hs = []

@@ -335,6 +335,18 @@ def linear(x, wt, bias, act_in=None, act_out=None, out=None):
     return out
 
 
+def ss_gather(T, Ct, bias, cursor, classes, keep, out=None):
+    """(scale, shift) rows of a replayed denoise step from the tables of ``UnetEngine.ss_tables``:
+    out[b] = (T[cursor] + Ct[keep[b] ? classes[b] : last row]) + bias — bitwise ``linear`` over the full embedding."""
+    B, N = classes.shape[0], T.shape[1]
+    if out is None:
+        out = _empty((B, N), T)
+    assert out.shape == (B, N) and out.is_contiguous() and Ct.shape[1] == N and bias.shape == (N,)
+    call('dmh_ss_gather', ptr(T), ptr(Ct), ptr(bias), ptr(cursor, torch.int32), ptr(classes, torch.int64),
+         ptr(keep, torch.uint8), Ct.shape[0] - 1, ptr(out), B, N)
+    return out
+
+
 # ------------------------------------------------------------------ sampler glue
 def assemble_input(a, b=None, m=None, reps=1, cpad=None):
     """(B,Ca,H,W) [+ (B,Cb,H,W) * (B,1,H,W)] NCHW -> NHWC (reps*B, H, W, cpad), zero padded."""

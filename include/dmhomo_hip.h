@@ -221,6 +221,14 @@ int dmh_class_embed(const int64_t* classes, const uint8_t* keep, const float* ta
 int dmh_linear(const float* x, int64_t x_stride, const float* wt, const float* bias, float* y, int64_t y_stride,
                int R, int in_dim, int out_dim, int act_in, int act_out, void* stream);
 
+/* The (scale, shift) rows of all ResnetBlocks (ResnetBlock.mlp CFG:220,231-235 over [time_mlp(t) | classes_mlp(c)], CFG:427,435)
+ * of a REPLAYED denoise step from tables: out[b][0..N) = (T[*cursor] + C[keep[b] ? classes[b] : ncls]) + bias, with T [S][N] the
+ * time half's partial sums of dmh_linear per denoise step and C [ncls+1][N] the class half's per class (last row: null
+ * embedding), both made by dmh_linear itself on inputs whose other half is zero; bitwise dmh_linear on the full input.
+ * cursor: the step cursor of dmh_sampler_seek (device); keep may be NULL (every class kept). */
+int dmh_ss_gather(const float* T, const float* C, const float* bias, const int32_t* cursor, const int64_t* classes,
+                  const uint8_t* keep, int ncls, float* out, int B, int N, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * K6  sampler glue (NCHW at the API boundary)
  * ------------------------------------------------------------------------------------- */
