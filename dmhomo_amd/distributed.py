@@ -21,7 +21,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    use_cuda = torch.cuda.is_available()
+    # an explicit backend='gloo' ARGUMENT asks for a host-only process group (the CPU plumbing tests), also on a box with
+    # GPUs; DMH_DIST_BACKEND=gloo (environment) keeps the ranks on the GPU and only swaps the transport
+    use_cuda = torch.cuda.is_available() and backend != 'gloo'
     if use_cuda:
         # DMH_SHARE_GPU=1 (tests on a one-GPU box): the ranks of the job time-share the visible GPUs; RCCL refuses two
         # ranks on one device, so such a job runs over gloo (DMH_DIST_BACKEND=gloo; the collectives then stage through host memory)
