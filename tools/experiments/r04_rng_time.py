@@ -21,3 +21,15 @@ for _ in range(200):
     ops.assemble_input(x, rf, mk, reps=1, cpad=12)
 e1.record(); torch.cuda.synchronize()
 print('assemble_input 25 rows 128x128 -> 12 channels NHWC: %.1f us per launch' % (e0.elapsed_time(e1) * 1e3 / 200))
+from dmhomo_amd.ops import call, ptr, lib
+for (B, n) in ((25, 16384), (25, 4096), (25, 1024)):
+    ns = lib().dmh_linattn_fused_splits(B, n)
+    partial = torch.randn(B, ns, 4, 1088, device=dev).abs()
+    ctx = torch.empty(B, 4, 32, 32, device=dev)
+    for _ in range(5):
+        call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(200):
+        call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
+    e1.record(); torch.cuda.synchronize()
+    print('linattn_merge B=%d n=%d (%d splits): %.1f us per launch' % (B, n, ns, e0.elapsed_time(e1) * 1e3 / 200))
