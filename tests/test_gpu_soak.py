@@ -165,3 +165,25 @@ def test_soak_ring_kernel_beside_a_conv_240_launches(ops, B):
         bad += int(not torch.equal(context(), alone))
     nb.join()
     assert bad == 0, f'{bad} of 240 launches differ from the launch on an idle chip'
+
+
+def test_soak_whole_step_is_reproducible_call_after_call():
+    """the whole headline step as it is benchmarked — dim 64, 128x128, bs 25, s_step 32, the two CFG passes concurrent on two
+    streams, the per-step graph replayed, noise keyed by sample — 16 calls under the same key: every call BITWISE the first
+    (round 4 ran 600 such calls, 6.3 M kernel launches: 0 differed; tools/experiments/step_soak.py)"""
+    from dmhomo_amd import cfg, ddpm
+    torch.manual_seed(0)
+    model = cfg.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+    model.cfg_mode = 'streams'
+    d = cfg.GaussianDiffusion(model, image_size=128, timesteps=1000, sampling_timesteps=32, objective='pred_x0').to(dev())
+    d.hip_graph = True
+    data, classes = next(ddpm.SyntheticConditions(128, 25, seed=1000, device=dev()))
+    rgb_flow, flow, mask = data[:, -5:-2].contiguous(), data[:, -2:].contiguous(), data[:, -6:-5].contiguous()
+
+    def run():
+        d.rng.key_by_sample(99, range(25), dev())
+        return d.sample(classes, rgb_flow, flow, mask)[0].clone()
+    first = run()
+    assert torch.isfinite(first).all()
+    bad = sum(int(not torch.equal(run(), first)) for _ in range(16))
+    assert bad == 0, f'{bad} of 16 calls differ from the first'
