@@ -233,8 +233,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help="launch every kernel from Python instead of replaying the "
                     "HIP graph of the sampling loop (cfg.GaussianDiffusion.hip_graph)")
     ap.add_argument('--no-roofline', action='store_true', help='skip the extra untimed step that carries the HIP events')
-    ap.add_argument('--variants', action='store_true',
-                    help='also time the opt-in dedup_dropped_rows mode (3 extra steps) and report it under "variants"')
+    ap.add_argument('--no-variants', action='store_true',
+                    help='skip the extra steps (after the timed region) that time cfg.Unet.dedup_dropped_rows and report it '
+                         'under "variants" (the headline `value` never includes it)')
     ap.add_argument('--workload', default='sample', choices=['sample', 'train'],
                     help="'train': the optimiser step of BASELINE configs[3] (16 images per GPU, gradients averaged over "
                          "RCCL) instead of the headline sampling loop; same launch contract, see tools/train_bench.py")
@@ -317,20 +318,30 @@ def main():
         torch.cuda.synchronize()
         log, ops.CONV_LOG = ops.CONV_LOG, None
         model.cfg_mode = args.cfg_mode
-    # ---- --variants: reported beside the headline, never as it: the opt-in de-duplication of the conditional pass's
-    # dropped rows (cfg.Unet.dedup_dropped_rows: identical outputs, B + kept rows per denoise step instead of 2B)
-    dedup_elapsed = 0.0
-    if args.variants:
-        diffusion.hip_graph = False                      # (the de-duplication reads its mask on the host every step)
-        model.cfg_mode, model.dedup_dropped_rows = 'batched', True
-        step()
+    # ---- variants: reported beside the headline, never as it: the opt-in de-duplication of the conditional pass's
+    # dropped rows (cfg.Unet.dedup_dropped_rows: identical samples, B + kept rows per denoise step instead of 2B), in the
+    # headline's own configuration (captured step, cfg_mode as above), timed after the timed region
+    dedup_elapsed, dedup_rows, dedup_steps = 0.0, None, max(2, min(args.steps, 5))
+    if not args.no_variants:
+        diffusion.hip_graph = use_graph
+        model.dedup_dropped_rows = True
+        step()                                           # (captures the de-duplicating step)
         fence()
+        base_draw = int(diffusion.rng.state[1].item())
         t1 = time.perf_counter()
-        for _ in range(2):
+        for _ in range(dedup_steps):
             step()
         fence()
-        dedup_elapsed = (time.perf_counter() - t1) / 2
-        model.cfg_mode, model.dedup_dropped_rows = args.cfg_mode, False
+        dedup_elapsed = (time.perf_counter() - t1) / dedup_steps
+        model.dedup_dropped_rows = False
+        # the UNet rows those steps computed: the keep masks are a pure function of (seed, sample id, draw index) — a
+        # sample() call makes 2 * s_step draws, the mask of denoise step k is draw 1 + 2k of the call
+        st_, kept = diffusion.rng.state.clone(), 0
+        for c_ in range(dedup_steps):
+            for k_ in range(args.s_step):
+                st_[1] = base_draw + c_ * 2 * args.s_step + 1 + 2 * k_
+                kept += int(ops.rng_keep_mask(diffusion.rng.sample_ids, st_, 1 - model.cond_drop_prob).sum().item())
+        dedup_rows = (hi - lo) + kept / (dedup_steps * args.s_step)
     rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed, dedup_elapsed], device=device, dtype=torch.float64)
@@ -366,16 +377,22 @@ def main():
                                      'fp32 accumulate, error at the fp32-accumulation level: DESIGN.md 3.1); '
                                      'DMH_CONV3_VARIANT=6 selects the exact-fp32 kernels'},
         }
-        if args.variants:
+        if not args.no_variants:
             res['variants'] = {'dedup_dropped_rows': {
                 'value': args.bs * world / dedup_elapsed, 'unit': 'images/s', 'ms_per_step': dedup_elapsed * 1e3,
-                'note': 'NOT the headline: opt-in cfg.Unet.dedup_dropped_rows — rows of the conditional pass whose class '
-                        'was dropped (p = 0.5, CFG:404) equal their null-pass rows and are computed once; bitwise identical '
-                        'samples (tests/test_gpu_unet.py::test_fullsize_rows_independent_and_cfg_modes_agree)'}}
+                'speedup_vs_value': (args.bs * world / dedup_elapsed) / (images / elapsed), 'steps': dedup_steps,
+                'hip_graph': use_graph, 'cfg_mode': args.cfg_mode,
+                'unet_rows_per_denoise_step': dedup_rows, 'unet_rows_per_denoise_step_full': 2 * (hi - lo),
+                'rows_note': 'rank 0: its null-pass rows + the mean number of conditional rows kept per denoise step',
+                'note': 'NOT the headline (`value` computes all 2B rows): opt-in cfg.Unet.dedup_dropped_rows — rows of the '
+                        'conditional pass whose class was dropped (p = 0.5, CFG:404,415-425) equal their null-pass rows and '
+                        'are not computed; the keep mask stays on the device (row subsets of include/dmhomo_hip.h) inside the '
+                        'captured step; bitwise identical samples (tests/test_gpu_dedup.py)'}}
         if log:
             res['roofline'] = roofline(log, args)
         if not args.no_cpu_baseline:         # rank 0's host cores, whatever N is (the other ranks wait at the barrier)
             big = args.dim * args.image_size > 64 * 128
+            torch.cuda.synchronize()
             res['cpu_baseline'] = cpu_baseline(args.dim, args.image_size, seconds=4.0 if big else 12.0,
                                                slice_bs=0 if big else args.bs,
                                                conds=(rgb_flow.cpu(), flow.cpu(), mask.cpu()))

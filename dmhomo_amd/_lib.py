@@ -20,7 +20,7 @@ c_int = C.c_int
 c_float = C.c_float
 
 
-ABI_VERSION = 400          # include/dmhomo_hip.h: DMH_ABI_VERSION
+ABI_VERSION = 500          # include/dmhomo_hip.h: DMH_ABI_VERSION
 
 
 class DmhConv(C.Structure):
@@ -29,7 +29,8 @@ class DmhConv(C.Structure):
                                           'stats')] + \
                [(n, C.c_int32) for n in ('B', 'Hin', 'Win', 'C0', 'C1', 'Cout', 'KH', 'KW', 'stride', 'upsample2')] + \
                [('in_bound', C.c_void_p), ('in_bound_n', C.c_int32), ('fin_n', C.c_int32), ('fin_w', C.c_void_p),
-                ('fin_b', C.c_void_p), ('fin_out', C.c_void_p), ('pix_stats', C.c_void_p), ('pix_eps', C.c_float)]
+                ('fin_b', C.c_void_p), ('fin_out', C.c_void_p), ('pix_stats', C.c_void_p), ('pix_eps', C.c_float),
+                ('rows', C.c_void_p)]
 
 
 class DmhPackJob(C.Structure):
@@ -55,18 +56,20 @@ SIGNATURES = {
     'dmh_pack_conv_weight_up2': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_conv_tiles': (c_int, [c_int, c_int, c_int, c_int]),
     'dmh_conv2d': (c_int, [C.POINTER(DmhConv), C.c_void_p]),
+    'dmh_rows_from_keep': (c_int, [C.c_void_p, c_int, c_int, C.c_void_p, C.c_void_p]),
     'dmh_gn_finalize': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int,
-                                c_float, C.c_void_p]),
+                                c_float, C.c_void_p, C.c_void_p]),
     'dmh_gn_finalize_bound': (c_int, [c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_int, c_int, c_int,
-                                      c_int, c_float, C.c_void_p]),
-    'dmh_gn_silu_residual': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
-    'dmh_gn_silu_residual_stats': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, C.c_void_p]),
-    'dmh_chan_layernorm': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),
+                                      c_int, c_float, C.c_void_p, C.c_void_p]),
+    'dmh_gn_silu_residual': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p, C.c_void_p]),
+    'dmh_gn_silu_residual_stats': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, C.c_void_p,
+                                           C.c_void_p]),
+    'dmh_chan_layernorm': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p, c_i64, C.c_void_p]),
     'dmh_linattn_splits': (c_int, [c_int]),
     'dmh_linattn_partial_floats': (c_i64, [c_int, c_int]),
-    'dmh_linattn_context': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
-    'dmh_linattn_merge': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
-    'dmh_linattn_apply': (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
+    'dmh_linattn_context': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p, C.c_void_p]),
+    'dmh_linattn_merge': (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p, C.c_void_p]),
+    'dmh_linattn_apply': (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p, C.c_void_p]),
     'dmh_conv_wgrad_workspace_floats': (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'dmh_conv_wgrad': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_int, C.c_void_p]),
@@ -106,19 +109,19 @@ SIGNATURES = {
     'dmh_resize_bilinear_u8': (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_i64, c_float,
                                        C.c_void_p]),
     'dmh_mask_open_nearest': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_i64, C.c_void_p]),
-    'dmh_pixel_stats': (c_int, [c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p]),
+    'dmh_pixel_stats': (c_int, [c_f32p, c_f32p, c_i64, c_int, c_float, C.c_void_p, c_i64, C.c_void_p]),
     'dmh_linattn_fused_pack_floats': (c_i64, [c_int]),
     'dmh_linattn_fused_pack': (c_int, [c_f32p, c_f32p, c_int, C.c_void_p]),
     'dmh_linattn_fused_splits': (c_int, [c_int, c_int]),
-    'dmh_linattn_fused_context': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
+    'dmh_linattn_fused_context': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p, C.c_void_p]),
     'dmh_linattn_out_pack_floats': (c_i64, []),
     'dmh_linattn_out_pack': (c_int, [c_f32p, c_f32p, C.c_void_p]),
     'dmh_linattn_fused_apply_out': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
-                                            c_int, c_int, c_float, c_float, C.c_void_p]),
-    'dmh_linattn_merge_n': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
+                                            c_int, c_int, c_float, c_float, C.c_void_p, C.c_void_p]),
+    'dmh_linattn_merge_n': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p, C.c_void_p]),
     'dmh_linattn_fused_apply': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float,
-                                        C.c_void_p]),
-    'dmh_attention': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p]),
+    'dmh_attention': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p, C.c_void_p]),
     'dmh_sinusoidal_embed': (c_int, [C.c_void_p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_class_embed': (c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_linear': (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_int, c_int,
@@ -128,8 +131,9 @@ SIGNATURES = {
                                    C.c_void_p]),
     'dmh_final_conv_nchw': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
     'dmh_sampler_step': (c_int, [C.POINTER(DmhStep), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64,
-                                 C.c_void_p]),
-    'dmh_sampler_step_dev': (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_void_p]),
+                                 C.c_void_p, c_i64, C.c_void_p]),
+    'dmh_sampler_step_dev': (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_void_p,
+                                     c_i64, C.c_void_p]),
     'dmh_sampler_seek': (c_int, [C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int, C.c_void_p, C.c_void_p, c_int,
                                  C.c_void_p]),
     'dmh_rng_indexed': (c_int, [c_f32p, c_int, c_i64, C.c_void_p, C.c_void_p, c_int, C.c_void_p]),

@@ -152,11 +152,13 @@ class Unet(nn.Module):
         return (self.rng.uniform(batch, device) < prob).to(torch.uint8)
 
     def _null_mask(self, batch, device):
-        """(batch,) uint8 zeros: every class dropped (the null pass, CFG:409) — allocated once, never written"""
-        z = self.__dict__.get('_null_keep')
-        if z is None or z.shape[0] != batch or z.device != torch.device(device):
-            z = torch.zeros((batch,), device=device, dtype=torch.uint8)
-            self.__dict__['_null_keep'] = z
+        """(batch,) uint8 zeros: every class dropped (the null pass, CFG:409) — one buffer per (batch, device), allocated once,
+        never written and never replaced: a captured denoise step holds its address for as long as the graph lives"""
+        cache = self.__dict__.setdefault('_null_keep', {})
+        key = (int(batch), str(torch.device(device)))
+        z = cache.get(key)
+        if z is None:
+            z = cache[key] = torch.zeros((batch,), device=device, dtype=torch.uint8)
         return z
 
     def _stem(self, x, rgb_flow, mask):
@@ -169,9 +171,10 @@ class Unet(nn.Module):
                                  mask.to(torch.float32).contiguous(), reps=1, cpad=eng.cin_pad)
         return eng.stem(xin)
 
-    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None, x0=None, first=None, out=None):
+    def _run(self, x, time, classes, rgb_flow, mask, keeps, taps=None, x0=None, first=None, out=None, rows=None):
         """rows [rep*B + b]: sample b under class-keep mask keeps[rep] -> (len(keeps)*B, out_dim, H, W).
-        first: engine.first_conv(x0) when the caller shares it between passes."""
+        first: engine.first_conv(x0) when the caller shares it between passes.
+        rows: ``ops.rows_from_keep`` list of the rows to compute (the others stay unwritten), or None for all."""
         eng = self._engine
         if x0 is None:
             x0 = self._stem(x, rgb_flow, mask)
@@ -189,9 +192,9 @@ class Unet(nn.Module):
             ss_all = torch.empty((len(keeps) * B, T.shape[1]), device=T.device, dtype=torch.float32)
             for r, k in enumerate(keeps):
                 ops.ss_gather(T, Ct, eng.mlp_b, cursor, classes, k, out=ss_all[r * B:(r + 1) * B])
-            return eng.trunk(x0, None, taps, first=first, out=out, ss_all=ss_all)
+            return eng.trunk(x0, None, taps, first=first, out=out, ss_all=ss_all, rows=rows)
         cond = eng.embed(time, [(classes, k) for k in keeps], len(keeps))
-        return eng.trunk(x0, cond, taps, first=first, out=out)
+        return eng.trunk(x0, cond, taps, first=first, out=out, rows=rows)
 
     def forward(self, x, time, classes, rgb_flow, mask, cond_drop_prob=None):
         cond_drop_prob = default(cond_drop_prob, self.cond_drop_prob)
@@ -208,10 +211,13 @@ class Unet(nn.Module):
     share_first_conv = __import__('os').environ.get('DMH_SHARE_FIRST_CONV', '1') != '0'
 
     def _cond_null(self, x, time, classes, rgb_flow, mask):
-        """the two passes of CFG:404,409: (cond logits, null logits)."""
+        """the two passes of CFG:404,409: (cond logits, null logits, computed).  computed is None — every row of the cond
+        logits was computed — or, with ``dedup_dropped_rows``, the (B,) uint8 class-keep mask: rows where it is 0 were left
+        UNWRITTEN in the cond logits and equal the null logits' rows (``ops.sampler_step(..., keep=computed)``)."""
         B = x.shape[0]
         keep = self._keep_mask(B, self.cond_drop_prob, x.device)
         null = self._null_mask(B, x.device)
+        dedup = bool(self.dedup_dropped_rows) and keep is not None
         if self.cfg_mode == 'streams':
             nsub = max(1, min(int(self.stream_splits), B))       # row sub-batches per pass (each on its own stream)
             nstreams = 2 * nsub
@@ -226,7 +232,7 @@ class Unet(nn.Module):
             null_out = torch.empty_like(cond_out)
             bounds = [(i * B) // nsub for i in range(nsub + 1)]
             si = 0
-            for k, dst in ((keep, cond_out), (null, null_out)):
+            for k, dst, sub in ((keep, cond_out, dedup), (null, null_out, False)):
                 for lo, hi in zip(bounds[:-1], bounds[1:]):
                     st = self._side[si]
                     si += 1
@@ -235,39 +241,24 @@ class Unet(nn.Module):
                         kk = None if k is None else k[lo:hi].contiguous()
                         fs = None if first is None else (first[0][lo:hi], first[1][lo:hi])
                         # (the pass writes its rows of the result itself: the fused final projection's destination)
-                        self._run(None, time[lo:hi], classes[lo:hi], None, None, [kk], x0=x0[lo:hi], first=fs, out=dst[lo:hi])
+                        self._run(None, time[lo:hi], classes[lo:hi], None, None, [kk], x0=x0[lo:hi], first=fs, out=dst[lo:hi],
+                                  rows=ops.rows_from_keep(kk) if sub else None)
             for st in self._side:
                 cur.wait_stream(st)
-            return cond_out, null_out
-        if self.dedup_dropped_rows and keep is not None:
-            return self._cond_null_dedup(x, time, classes, rgb_flow, mask, keep, null)
-        both = self._run(x, time, classes, rgb_flow, mask, [keep, null])
-        return both[:B], both[B:]
+            return cond_out, null_out, (keep if dedup else None)
+        both = self._run(x, time, classes, rgb_flow, mask, [keep, null],
+                         rows=ops.rows_from_keep(keep, extra=B) if dedup else None)
+        return both[:B], both[B:], (keep if dedup else None)
 
-    # OPT-IN, off by default (bench.py's headline keeps it off).  The reference's conditional pass draws a class-dropout
-    # mask with p = 0.5 (CFG:404 -> CFG:415,422): a dropped row of that pass has exactly the inputs of the same sample's
-    # row in the null pass, so its logits equal the null logits and the guided output is the null output.  With this
-    # switch those duplicate rows are computed once: B + (kept rows) UNet rows instead of 2B, bitwise the same result
-    # (rows are independent of their batch — tests pin that).  Costs one host read of the mask per denoise step.
+    # OPT-IN, off by default (bench.py's headline keeps it off and reports it under "variants").  The reference's conditional
+    # pass draws a class-dropout mask with p = 0.5 (CFG:404 -> CFG:415,422), also while sampling: a dropped row of that pass
+    # has exactly the inputs of the same sample's row in the null pass, so its logits equal the null logits and the guided
+    # output is the null output.  With this switch those duplicate rows are not computed: the mask never leaves the device —
+    # ``ops.rows_from_keep`` turns it into the list of active rows that every launch of the conditional pass takes
+    # (include/dmhomo_hip.h, "Row subsets": the captured B-row grid stays, workgroups of inactive rows retire at once), and the
+    # sampler step reads the null logits where the mask is 0.  B + (kept rows) UNet rows per step instead of 2B, the result
+    # bit for bit the same (rows are independent of their batch — tests pin that), in every cfg_mode and under hip_graph.
     dedup_dropped_rows = False
-
-    def _cond_null_dedup(self, x, time, classes, rgb_flow, mask, keep, null):
-        B = x.shape[0]
-        sel = keep.to(torch.bool).cpu().nonzero().flatten()
-        n = int(sel.numel())
-        x0 = self._stem(x, rgb_flow, mask)
-        if n == 0:
-            out = self._run(None, time, classes, None, None, [null], x0=x0)
-            return out, out
-        seld = sel.to(x.device)
-        rows = torch.cat([seld, torch.arange(B, device=x.device)])
-        k = torch.cat([torch.ones((n,), device=x.device, dtype=torch.uint8), null])
-        out = self._run(None, time.index_select(0, rows), classes.index_select(0, rows), None, None, [k],
-                        x0=x0.index_select(0, rows))
-        null_out = out[n:]
-        cond_out = null_out.clone()
-        cond_out.index_copy_(0, seld, out[:n])
-        return cond_out, null_out
 
     def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
         """CFG:403-410: ``forward(*args, **kwargs)``; for cond_scale != 1 blended with ``forward(*args, cond_drop_prob=1.,
@@ -277,10 +268,10 @@ class Unet(nn.Module):
         if 'cond_drop_prob' in kwargs or len(args) > 5:
             raise TypeError("forward() got multiple values for keyword argument 'cond_drop_prob'")   # as CFG:409 would
         x, time, classes, rgb_flow, mask = _bind_forward(self.forward, args, kwargs)
-        logits, null = self._cond_null(x, time, classes, rgb_flow, mask)
+        logits, null, computed = self._cond_null(x, time, classes, rgb_flow, mask)
         step = DmhStep(objective=ops.OBJECTIVE['pred_x0'], clip=0, mode=ops.MODE_LAST, cond_scale=float(cond_scale),
                        sqrt_recip_ac=1., sqrt_recipm1_ac=1.)
-        out, _, _ = ops.sampler_step(step, logits, null, logits, None, want_x_start=False)
+        out, _, _ = ops.sampler_step(step, logits, null, null, None, want_x_start=False, keep=computed)
         return out
 
 
@@ -420,24 +411,25 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         return t0
 
     def _network(self, x, t, classes, rgb_flow, mask, cond_scale):
+        """-> (cond logits, null logits or None, computed-rows mask or None): see Unet._cond_null"""
         if cond_scale == 1:
-            return self.model.forward(x, t, classes, rgb_flow, mask), None
+            return self.model.forward(x, t, classes, rgb_flow, mask), None, None
         return self.model._cond_null(x, t, classes, rgb_flow, mask)
 
     def model_predictions(self, x, t, classes, rgb_flow, mask, cond_scale=3., clip_x_start=False):
         """CFG:610-630.  One timestep for the whole batch (what the samplers pass): blend, objective branch and clamp in
         ONE pass of dmh_sampler_step; a timestep per row (p_losses-style callers): the same arithmetic row by row."""
         host = self._host()
-        cond, null = self._network(x, t, classes, rgb_flow, mask, cond_scale)
+        cond, null, computed = self._network(x, t, classes, rgb_flow, mask, cond_scale)
         t0 = self._uniform_time(t)
         if t0 is None:
             if null is not None:                             # null + (cond - null) * cond_scale, CFG:410
                 blend = DmhStep(objective=ops.OBJECTIVE['pred_x0'], clip=0, mode=ops.MODE_LAST,
                                 cond_scale=float(cond_scale), sqrt_recip_ac=1., sqrt_recipm1_ac=1.)
-                cond, _, _ = ops.sampler_step(blend, cond, null, cond, None, want_x_start=False)
+                cond, _, _ = ops.sampler_step(blend, cond, null, null, None, want_x_start=False, keep=computed)
             return self._predictions_per_row(cond, x.contiguous(), t, clip_x_start)
         step = self._step(host, t0, ops.MODE_LAST, cond_scale, clip_x_start)
-        _, x_start, pred_noise = ops.sampler_step(step, cond, null, x.contiguous(), None, True, True)
+        _, x_start, pred_noise = ops.sampler_step(step, cond, null, x.contiguous(), None, True, True, keep=computed)
         return ModelPrediction(pred_noise, x_start)
 
     def p_mean_variance(self, x, t, classes, cond_scale, clip_denoised=True):
@@ -476,7 +468,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
         img = self.rng.randn(shape, device).contiguous()
         for time, time_next in ddim_pairs(self.num_timesteps, self.sampling_timesteps):
             time_cond = torch.full((batch,), time, device=device, dtype=torch.long)
-            cond, null = self._network(img, time_cond, classes, rgb_flow, mask, cond_scale)
+            cond, null, computed = self._network(img, time_cond, classes, rgb_flow, mask, cond_scale)
             if time_next < 0:
                 step = self._step(host, time, ops.MODE_LAST, cond_scale, clip_denoised)
                 noise = None
@@ -484,7 +476,7 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                 step = self._step(host, time, ops.MODE_DDIM, cond_scale, clip_denoised,
                                   self._ddim_coef(host, time, time_next))
                 noise = self.rng.randn(shape, device).contiguous()
-            img, x_start, _ = ops.sampler_step(step, cond, null, img, noise, want_x_start=trace is not None)
+            img, x_start, _ = ops.sampler_step(step, cond, null, img, noise, want_x_start=trace is not None, keep=computed)
             if trace is not None:
                 trace.append({'time': time, 'x_start': x_start, 'img': img})
         img = ops.affine(img, 0.5, 0.5)                      # unnormalize_to_zero_to_one, CFG:709
@@ -534,9 +526,6 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                str(device), self.rng.graph_key())
         st = self.__dict__.get('_graph_state')
         if st is None or st['key'] != key:
-            if self.model.dedup_dropped_rows:
-                raise RuntimeError('hip_graph: dedup_dropped_rows reads the class-dropout mask on the host every step and '
-                                   'cannot be captured')
             steps, times = [], []
             for time, time_next in ddim_pairs(self.num_timesteps, self.sampling_timesteps):
                 if time_next < 0:
@@ -558,14 +547,14 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                 st['ss_tab'] = (T_tab, C_tab, cursor)
 
             def mid():                                       # one denoise step of CFG:684-707, in place on st['img']
-                cond, null = self._network(st['img'], st['tcond'], ins[0], st['rf'], ins[2], cond_scale)
+                cond, null, computed = self._network(st['img'], st['tcond'], ins[0], st['rf'], ins[2], cond_scale)
                 noise = self.rng.randn(shape, device).contiguous()
-                ops.sampler_step_dev(cur, cond, null, st['img'], noise, out=st['img'])
+                ops.sampler_step_dev(cur, cond, null, st['img'], noise, out=st['img'], keep=computed)
                 ops.sampler_seek(cursor, -1, table, tt, cur, st['tcond'])
 
             def last():                                      # CFG:693-695 + unnormalize, CFG:709
-                cond, null = self._network(st['img'], st['tcond'], ins[0], st['rf'], ins[2], cond_scale)
-                x0 = ops.sampler_step_dev(cur, cond, null, st['img'], None)
+                cond, null, computed = self._network(st['img'], st['tcond'], ins[0], st['rf'], ins[2], cond_scale)
+                x0 = ops.sampler_step_dev(cur, cond, null, st['img'], None, keep=computed)
                 return ops.affine(x0, 0.5, 0.5)
             # eager warm-up of both bodies on a side stream (first-launch work: LDS attributes, side streams), as
             # torch.cuda.graphs asks for; the device RNG state is put back afterwards, so the capturing call consumes

@@ -17,8 +17,11 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // pass 1: per split, per head: m_d = max_n k[d,n]; p = exp(k - m); s_d = sum p; ctx[d][e] = sum_n p[d,n] v[e,n]
 // (softmax over the n pixels is finished in the merge).  The split's k values live in registers.
 __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv,
-                                                              float* __restrict__ partial, int n, int nsplit) {
-  const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+                                                              float* __restrict__ partial, int n, int nsplit,
+                                                              const int32_t* __restrict__ rows) {
+  const int jb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  if (rows && jb >= rows[0]) return;   // (a row subset, common.h: the workgroups of inactive rows retire)
+  const int b = dmh_rows_phys(rows, jb);
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
   const int d = lane & 31, half = lane >> 5;
   const int p0 = sp * LA_NS;
@@ -69,9 +72,10 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
 // merge the splits: M = max m; S = sum s*exp(m-M); ctx = sum ctx*exp(m-M) / S / n
 __global__ __launch_bounds__(1024) void linattn_merge_kernel(const float* __restrict__ partial,
                                                              float* __restrict__ ctx, int n, int nsplit,
-                                                             float* __restrict__ ms) {
-  const int bh = blockIdx.x;  // b*4 + h
-  const int b = bh >> 2, h = bh & 3;
+                                                             float* __restrict__ ms, const int32_t* __restrict__ rows) {
+  if (rows && (int)(blockIdx.x >> 2) >= rows[0]) return;   // (a row subset, common.h)
+  const int b = dmh_rows_phys(rows, blockIdx.x >> 2), h = blockIdx.x & 3;
+  const int bh = b * 4 + h;
   const int d = threadIdx.x >> 5, e = threadIdx.x & 31;
   const float* base = partial + ((size_t)b * nsplit * 4 + h) * LA_PART;
   const size_t stride = (size_t)4 * LA_PART;
@@ -97,8 +101,11 @@ __global__ __launch_bounds__(1024) void linattn_merge_kernel(const float* __rest
 #define LA_TILES 4  // 32-pixel tiles per wave
 __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ qkv,
                                                             const float* __restrict__ ctx, float* __restrict__ out,
-                                                            int n, int nblk, float scale) {
-  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+                                                            int n, int nblk, float scale,
+                                                            const int32_t* __restrict__ rows) {
+  const int jb = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  if (rows && jb >= rows[0]) return;   // (a row subset, common.h)
+  const int b = dmh_rows_phys(rows, jb);
   const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
   const int i = lane & 31, half = lane >> 5;
   const float* cb = ctx + ((size_t)(b * 4 + h)) * 1024;
@@ -158,13 +165,15 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
 // on accumulator rows (registers + lane half) and P^T is already in B-operand position for
 // out^T[e][query] += V^T[e][key] P^T[key][query].  One wave per (sample, head, 32 queries).
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n,
-                                                        int qtiles, float scale) {
+                                                        int qtiles, float scale, const int32_t* __restrict__ rows) {
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int i = lane & 31, half = lane >> 5;
   const int qt = wid % qtiles;
   const int bh = wid / qtiles;
-  const int h = bh & 3, b = bh >> 2;
+  const int h = bh & 3;
+  if (rows && (bh >> 2) >= rows[0]) return;   // (a row subset, common.h; waves are independent: no workgroup barrier below)
+  const int b = dmh_rows_phys(rows, bh >> 2);
   const float* base = qkv + (size_t)b * n * 384;
   const int q0 = qt * 32;
 
@@ -269,27 +278,28 @@ extern "C" int64_t dmh_linattn_partial_floats(int B, int n) {
   return (int64_t)B * dmh_linattn_splits(n) * 4 * LA_PART;
 }
 
-extern "C" int dmh_linattn_context(const float* qkv, float* partial, int B, int n, void* stream) {
+extern "C" int dmh_linattn_context(const float* qkv, float* partial, int B, int n, const int32_t* rows, void* stream) {
   DMH_REQUIRE(qkv && partial && B > 0 && n > 0, "dmh_linattn_context: bad arguments");
   const int ns = dmh_linattn_splits(n);
-  hipLaunchKernelGGL(linattn_context_kernel, dim3(B * ns), dim3(256), 0, (hipStream_t)stream, qkv, partial, n, ns);
+  hipLaunchKernelGGL(linattn_context_kernel, dim3(B * ns), dim3(256), 0, (hipStream_t)stream, qkv, partial, n, ns, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_context");
   return DMH_OK;
 }
 
-extern "C" int dmh_linattn_merge(const float* partial, float* ctx, int B, int n, void* stream) {
+extern "C" int dmh_linattn_merge(const float* partial, float* ctx, int B, int n, const int32_t* rows, void* stream) {
   DMH_REQUIRE(partial && ctx && B > 0 && n > 0, "dmh_linattn_merge: bad arguments");
   hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n,
-                     dmh_linattn_splits(n), (float*)nullptr);
+                     dmh_linattn_splits(n), (float*)nullptr, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_merge");
   return DMH_OK;
 }
 
 // same merge for partials produced with another split count (linattn_fused.hip)
-extern "C" int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, void* stream) {
+extern "C" int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, const int32_t* rows,
+                                   void* stream) {
   DMH_REQUIRE(partial && ctx && B > 0 && n > 0 && nsplit > 0, "dmh_linattn_merge_n: bad arguments");
   hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n, nsplit,
-                     (float*)nullptr);
+                     (float*)nullptr, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_merge_n");
   return DMH_OK;
 }
@@ -298,26 +308,26 @@ extern "C" int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int 
 extern "C" int dmh_linattn_merge_ms(const float* partial, float* ctx, float* ms, int B, int n, void* stream) {
   DMH_REQUIRE(partial && ctx && ms && B > 0 && n > 0, "dmh_linattn_merge_ms: bad arguments");
   hipLaunchKernelGGL(linattn_merge_kernel, dim3(B * 4), dim3(1024), 0, (hipStream_t)stream, partial, ctx, n,
-                     dmh_linattn_splits(n), ms);
+                     dmh_linattn_splits(n), ms, (const int32_t*)nullptr);
   DMH_CHECK_LAUNCH("dmh_linattn_merge_ms");
   return DMH_OK;
 }
 
 extern "C" int dmh_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int n, float scale,
-                                 void* stream) {
+                                 const int32_t* rows, void* stream) {
   DMH_REQUIRE(qkv && ctx && out && B > 0 && n > 0, "dmh_linattn_apply: bad arguments");
   const int nblk = cdiv(n, 32 * LA_TILES);
   hipLaunchKernelGGL(linattn_apply_kernel, dim3(B * nblk), dim3(256), 0, (hipStream_t)stream, qkv, ctx, out, n, nblk,
-                     scale);
+                     scale, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_apply");
   return DMH_OK;
 }
 
-extern "C" int dmh_attention(const float* qkv, float* out, int B, int n, float scale, void* stream) {
+extern "C" int dmh_attention(const float* qkv, float* out, int B, int n, float scale, const int32_t* rows, void* stream) {
   DMH_REQUIRE(qkv && out && B > 0 && n > 0, "dmh_attention: bad arguments");
   const int qtiles = cdiv(n, 32);
   const int waves = B * 4 * qtiles;  // always a multiple of 4: one workgroup = the 4 heads' waves in flight
-  hipLaunchKernelGGL(attention_kernel, dim3(waves / 4), dim3(256), 0, (hipStream_t)stream, qkv, out, n, qtiles, scale);
+  hipLaunchKernelGGL(attention_kernel, dim3(waves / 4), dim3(256), 0, (hipStream_t)stream, qkv, out, n, qtiles, scale, rows);
   DMH_CHECK_LAUNCH("dmh_attention");
   return DMH_OK;
 }

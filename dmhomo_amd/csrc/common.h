@@ -148,5 +148,13 @@ __device__ __forceinline__ void dmh_split8(const float (&x)[8], float s, dmh_hal
   r = __builtin_bit_cast(dmh_half8, rr);
 }
 
+// ---- row subsets of a batched launch (de-duplication of the classifier-free-guidance passes, CFG:403-425).
+// rows == nullptr: logical row j of the launch is physical row (sample slot) j, j < B.  Otherwise rows[0] = n <= B active
+// rows and rows[1 + j] = the physical row of logical row j < n (dmh_rows_from_keep).  The launch keeps its full B-row grid —
+// n is device data, so the launch can sit in a captured graph — and a workgroup whose logical row is >= n retires before
+// it touches memory; tensors are indexed by PHYSICAL row, so nothing is gathered or scattered.
+__device__ __forceinline__ int dmh_rows_n(const int32_t* rows, int B) { return rows ? rows[0] : B; }
+__device__ __forceinline__ int dmh_rows_phys(const int32_t* rows, int j) { return rows ? rows[1 + j] : j; }
+
 // input-channel chunk width of the conv variants (must agree between pack and kernel)
 static inline int conv_kc(int KH, int stride) { return (KH == 7 || stride == 2) ? 16 : 32; }

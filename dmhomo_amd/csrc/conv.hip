@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256, WPE) void conv_igemm_kernel(ConvArgs p) {
   const int tx = t % p.tilesX;
   t /= p.tilesX;
   const int ty = t % p.tilesY;
-  const int b = t / p.tilesY;
+  if (t / p.tilesY >= dmh_rows_n(p.rows, p.B)) return;  // (DmhConv.rows: the workgroups of inactive rows retire)
+  const int b = dmh_rows_phys(p.rows, t / p.tilesY);
   const int nt = blockIdx.y;
   const int n0 = nt * 64;
   const int tile_in_sample = ty * p.tilesX + tx;

@@ -27,6 +27,7 @@ struct ConvArgs {
   int nch0, nch1, tilesX, tilesY;
   int ablate;  // diagnostic builds only (DMH_STAMPS): bit 0 skips staging + transform, bit 1 skips the matrix phase
   int xcd;     // 1: workgroup ids are re-dealt so that each XCD (id % 8) walks a contiguous run of tiles (DMH_CONV_XCD)
+  const int32_t* rows;  // DmhConv.rows: null, or the active row subset of this launch (common.h: dmh_rows_n / dmh_rows_phys)
 };
 
 
@@ -68,6 +69,7 @@ static inline ConvArgs fill_conv_args(const DmhConv* d, int Hout, int Wout, int 
     return e ? atoi(e) : 1;
   }();
   a.xcd = xcd;
+  a.rows = d->rows;
   return a;
 }
 

@@ -130,9 +130,19 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   // Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own L2: re-deal the ids so that
   // XCD k walks the k-th contiguous run of (cout tile, sample, tile row, tile column) — vertically adjacent tiles, whose
   // halos overlap, then run at the same time on the same L2.
-  int t = blockIdx.x, by = blockIdx.y;
+  int t = blockIdx.x, by = blockIdx.y, nb = gridDim.x;
+  if (p.rows) {
+    // a row subset (DmhConv.rows): the first (tiles per sample) x n x gridDim.y workgroups of the captured B-row grid do the
+    // work of the n active rows — re-dealt over the XCDs below as a grid of that size, so every XCD keeps an equal share
+    // whatever n is — and the rest retire here
+    nb = p.tilesX * p.tilesY * p.rows[0];
+    const int lin = t + by * (int)gridDim.x;
+    if (lin >= nb * (int)gridDim.y) return;
+    t = lin % nb;
+    by = lin / nb;
+  }
   if (p.xcd) {
-    const int nb = gridDim.x, total = nb * gridDim.y, lin = t + by * nb;
+    const int total = nb * gridDim.y, lin = t + by * nb;
     const int q = total >> 3, r = total & 7, xcd = lin & 7, local = lin >> 3;
     const int nl = xcd * q + min(xcd, r) + local;
     t = nl % nb;
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
   const int tx = t % p.tilesX;
   t /= p.tilesX;
   const int ty = t % p.tilesY;
-  const int b = t / p.tilesY;
+  const int b = dmh_rows_phys(p.rows, t / p.tilesY);
   const int nt = UPS == 3 ? wm * (int)gridDim.y + by : by * WN + wn;  // UPS == 3: virtual channels [parity][cout tile]
   const int n0 = UPS == 3 ? by * 64 : nt * 64;                          // output channels of this wave
 

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256 * G, 2) void conv_wino_kernel(ConvArgs p) {
   const int tx0 = t % p.tilesX;
   t /= p.tilesX;
   const int ty0 = t % p.tilesY;
-  const int b = t / p.tilesY;
+  if (t / p.tilesY >= dmh_rows_n(p.rows, p.B)) return;  // (DmhConv.rows: the workgroups of inactive rows retire)
+  const int b = dmh_rows_phys(p.rows, t / p.tilesY);
   const int nt = blockIdx.y * G + gq;
   const int n0 = nt * 64;
   const int tile_in_sample = ty0 * p.tilesX + tx0;

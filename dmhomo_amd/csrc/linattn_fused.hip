@@ -271,11 +271,14 @@ template <int RES>
 __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const uint4* __restrict__ wkv,
                                                             const float* __restrict__ oscale, float* __restrict__ partial,
-                                                            int n, int C, int nsplit, int tiles) {
+                                                            int n, int C, int nsplit, int tiles,
+                                                            const int32_t* __restrict__ rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* tiles_lds = smem;  // two staging tiles
 
-  const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int jb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  if (rows && jb >= rows[0]) return;   // (a row subset, common.h: the workgroups of inactive rows retire)
+  const int b = dmh_rows_phys(rows, jb);
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
   const int nch = C / KC;
@@ -500,12 +503,15 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const uint4* __restrict__ wkv,
                                                             const float* __restrict__ oscale, float* __restrict__ partial,
-                                                            int n, int C, int nsplit, int tiles) {
+                                                            int n, int C, int nsplit, int tiles,
+                                                            const int32_t* __restrict__ rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* tiles_lds = smem;  // two sets of two staging tiles, then the raw ring
   constexpr int RES = 2;            // C == 64: both chunks' weight fragments stay in registers
 
-  const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int jb = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  if (rows && jb >= rows[0]) return;   // (a row subset, common.h: the workgroups of inactive rows retire)
+  const int b = dmh_rows_phys(rows, jb);
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
 
@@ -767,7 +773,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
                                                             const float* __restrict__ g, const uint4* __restrict__ wq,
                                                             const float* __restrict__ oscale, const float* __restrict__ ctxm,
                                                             float* __restrict__ out, int n, int C, int nblk, int tiles,
-                                                            float scale, FuseOut fo) {
+                                                            float scale, FuseOut fo, const int32_t* __restrict__ rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NBUF = FUSE ? 1 : 2;
   unsigned char* tiles_lds = smem;
@@ -777,7 +783,9 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
   if (FUSE && threadIdx.x == 0) st4(hx_slot, make_float4(1.f, 1.f, 1.f, 1.f));   // (the first staging barrier publishes it)
 #endif
 
-  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  const int jb = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+  if (rows && jb >= rows[0]) return;   // (a row subset, common.h)
+  const int b = dmh_rows_phys(rows, jb);
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
   const int nch = C / KC;
@@ -1208,7 +1216,7 @@ extern "C" int dmh_linattn_fused_splits(int B, int n) { return cdiv(cdiv(n, TP),
 
 // pass 1: partial[B][splits][4][LA_PART]  (then dmh_linattn_merge with the same split count)
 extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, const float* ln_g, const float* wpack,
-                                         float* partial, int B, int n, int C, void* stream) {
+                                         float* partial, int B, int n, int C, const int32_t* rows, void* stream) {
   DMH_REQUIRE(x && stats && ln_g && wpack && partial, "dmh_linattn_fused_context: null pointer");
   DMH_REQUIRE(B > 0 && n > 0 && C > 0 && C % KC == 0, "dmh_linattn_fused_context: bad shape (C=%d)", C);
   const int tiles = fused_tiles(B, n), nsplit = cdiv(cdiv(n, TP), tiles);
@@ -1227,20 +1235,21 @@ extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, con
       attr = true;
     }
     hipLaunchKernelGGL(linattn_kv_ring_kernel, dim3(B * nsplit), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wkv,
-                       osc_kv, partial, n, C, nsplit, tiles);
+                       osc_kv, partial, n, C, nsplit, tiles, rows);
   } else if (C == 2 * KC)
     hipLaunchKernelGGL(linattn_kv_kernel<2>, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
-                       wkv, osc_kv, partial, n, C, nsplit, tiles);
+                       wkv, osc_kv, partial, n, C, nsplit, tiles, rows);
   else
     hipLaunchKernelGGL(linattn_kv_kernel<0>, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
-                       wkv, osc_kv, partial, n, C, nsplit, tiles);
+                       wkv, osc_kv, partial, n, C, nsplit, tiles, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_context");
   return DMH_OK;
 }
 
 // pass 2: out[B][n][128]
 extern "C" int dmh_linattn_fused_apply(const float* x, const float* stats, const float* ln_g, const float* wpack,
-                                       const float* ctx, float* out, int B, int n, int C, float scale, void* stream) {
+                                       const float* ctx, float* out, int B, int n, int C, float scale, const int32_t* rows,
+                                       void* stream) {
   DMH_REQUIRE(x && stats && ln_g && wpack && ctx && out, "dmh_linattn_fused_apply: null pointer");
   DMH_REQUIRE(B > 0 && n > 0 && C > 0 && C % KC == 0, "dmh_linattn_fused_apply: bad shape (C=%d)", C);
   const int tiles = fused_tiles(B, n), nblk = cdiv(cdiv(n, TP), tiles);
@@ -1248,7 +1257,7 @@ extern "C" int dmh_linattn_fused_apply(const float* x, const float* stats, const
   const float* osc_q = wpack + (int64_t)C * 384;
   FuseOut fo = {};
   hipLaunchKernelGGL(linattn_qo_kernel<false>, dim3(B * nblk), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats,
-                     ln_g, wq, osc_q, ctx, out, n, C, nblk, tiles, scale, fo);
+                     ln_g, wq, osc_q, ctx, out, n, C, nblk, tiles, scale, fo, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_apply");
   return DMH_OK;
 }
@@ -1306,7 +1315,7 @@ extern "C" int dmh_linattn_out_pack(const float* w_out, float* wpack, void* stre
 extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, const float* ln_g, const float* wpack,
                                            const float* ctx, const float* wopack, const float* out_bias,
                                            const float* out_ln_g, float* y, int B, int n, int C, float scale,
-                                           float eps, void* stream) {
+                                           float eps, const int32_t* rows, void* stream) {
   DMH_REQUIRE(x && stats && ln_g && wpack && ctx && wopack && out_bias && out_ln_g && y,
               "dmh_linattn_fused_apply_out: null pointer");
   DMH_REQUIRE(B > 0 && n > 0 && C == 64, "dmh_linattn_fused_apply_out: only C == 64 (got %d)", C);
@@ -1332,7 +1341,7 @@ extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, c
     attr = true;
   }
   hipLaunchKernelGGL(linattn_qo_kernel<true>, dim3(B * nblk), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wq,
-                     osc_q, ctx, nullptr, n, C, nblk, tiles, scale, fo);
+                     osc_q, ctx, nullptr, n, C, nblk, tiles, scale, fo, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_apply_out");
   return DMH_OK;
 }

@@ -12,10 +12,13 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ beta, const float* __restrict__ ss,
                                                           int64_t ss_stride, float* __restrict__ coef, int C, int groups,
                                                           int hw, float eps, float* __restrict__ mr,
-                                                          float* __restrict__ bound) {
+                                                          float* __restrict__ bound, const int32_t* __restrict__ rows) {
   __shared__ double red[2][4];
   __shared__ float bred[4];
-  const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+  const int jb = blockIdx.x / groups, g = blockIdx.x % groups;
+  if (jb >= dmh_rows_n(rows, gridDim.x / groups)) return;   // (a row subset: inactive rows retire, common.h)
+  const int b = dmh_rows_phys(rows, jb);
+  const int bg = b * groups + g;
   const int cg = C / groups;
   const int lane = threadIdx.x;
   double s1 = 0.0, s2 = 0.0;
@@ -44,8 +47,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
   const float meanf = (float)mean;
   if (mr && lane == 0) {  // saved for the backward pass: (mean, rstd) of this (sample, group)
-    mr[(size_t)blockIdx.x * 2 + 0] = meanf;
-    mr[(size_t)blockIdx.x * 2 + 1] = rstd;
+    mr[(size_t)bg * 2 + 0] = meanf;
+    mr[(size_t)bg * 2 + 1] = rstd;
   }
   // bound (optional): an upper bound of |a*x + b| over every element x of this (sample, group), for a consumer that needs
   // the magnitude of its prologue's input without looking at the data (conv_f16x3.hip's block scale): |x - mean| <=
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     for (int off = 32; off; off >>= 1) bmax = fmaxf(bmax, __shfl_xor(bmax, off));
     if ((lane & 63) == 0) bred[lane >> 6] = bmax;
     __syncthreads();
-    if (lane == 0) bound[blockIdx.x] = fmaxf(fmaxf(bred[0], bred[1]), fmaxf(bred[2], bred[3]));
+    if (lane == 0) bound[bg] = fmaxf(fmaxf(bred[0], bred[1]), fmaxf(bred[2], bred[3]));
   }
 }
 
@@ -88,15 +91,20 @@ template <int LPP>
 __global__ __launch_bounds__(256) void gn_silu_residual_kernel(const float* __restrict__ y,
                                                                const float* __restrict__ coef,
                                                                const float* __restrict__ res, float* __restrict__ out,
-                                                               int64_t per_sample4, int C, int64_t total4,
-                                                               float* __restrict__ pstats, float eps) {
+                                                               int64_t per_sample4, int C, int64_t total4_all,
+                                                               float* __restrict__ pstats, float eps,
+                                                               const int32_t* __restrict__ rows) {
   const int C4 = C >> 2;
   const int lane = threadIdx.x & 63;
+  // (a row subset, common.h: the flat index walks the active rows; tensors are addressed by physical row)
+  const int64_t total4 = rows ? per_sample4 * rows[0] : total4_all;
   for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 - lane < total4; i0 += (int64_t)gridDim.x * 256) {
     const bool ok = i0 < total4;
     if (LPP == 0 && !ok) break;
-    const int64_t i = ok ? i0 : total4 - 1;
-    const int b = (int)(i / per_sample4);
+    const int64_t il = ok ? i0 : total4 - 1;
+    const int jb = (int)(il / per_sample4);
+    const int b = dmh_rows_phys(rows, jb);
+    const int64_t i = il + (int64_t)(b - jb) * per_sample4;
     const int c = (int)(i % C4) * 4;
     const float4 a = ld4(coef + (size_t)(b * 2 + 0) * C + c);
     const float4 bb = ld4(coef + (size_t)(b * 2 + 1) * C + c);
@@ -132,12 +140,15 @@ __global__ __launch_bounds__(256) void gn_silu_residual_kernel(const float* __re
 template <int LPP, int NV>
 __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                              const float* __restrict__ res, float* __restrict__ out,
-                                                             int64_t npix, int C, float eps) {
+                                                             int64_t npix_all, int C, float eps,
+                                                             const int32_t* __restrict__ rows, int64_t pix_per_row) {
   const int C4 = C >> 2;
   const int sub = threadIdx.x % LPP;
   const int64_t pix_per_block = 256 / LPP;
-  for (int64_t pix = (int64_t)blockIdx.x * pix_per_block + threadIdx.x / LPP; pix < npix;
-       pix += (int64_t)gridDim.x * pix_per_block) {
+  const int64_t npix = rows ? pix_per_row * rows[0] : npix_all;   // (a row subset, common.h)
+  for (int64_t pl = (int64_t)blockIdx.x * pix_per_block + threadIdx.x / LPP; pl < npix;
+       pl += (int64_t)gridDim.x * pix_per_block) {
+    const int64_t pix = rows ? (int64_t)rows[1 + pl / pix_per_row] * pix_per_row + pl % pix_per_row : pl;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -185,11 +196,11 @@ __global__ __launch_bounds__(256) void chan_layernorm_kernel(const float* __rest
 
 extern "C" int dmh_gn_finalize(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
                                int64_t ss_stride, float* coef, int B, int C, int groups, int hw, float eps,
-                               void* stream) {
+                               const int32_t* rows, void* stream) {
   DMH_REQUIRE(stats && gamma && beta && coef, "dmh_gn_finalize: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize: bad shape");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
-                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr, (float*)nullptr);
+                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr, (float*)nullptr, rows);
   DMH_CHECK_LAUNCH("dmh_gn_finalize");
   return DMH_OK;
 }
@@ -198,11 +209,11 @@ extern "C" int dmh_gn_finalize(const float* stats, int tiles, const float* gamma
 // were taken from — DmhConv.in_bound of the conv that applies this affine in its prologue
 extern "C" int dmh_gn_finalize_bound(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
                                      int64_t ss_stride, float* coef, float* bound, int B, int C, int groups, int hw,
-                                     float eps, void* stream) {
+                                     float eps, const int32_t* rows, void* stream) {
   DMH_REQUIRE(stats && gamma && beta && coef && bound, "dmh_gn_finalize_bound: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize_bound: bad shape");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
-                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr, bound);
+                     ss, ss_stride, coef, C, groups, hw, eps, (float*)nullptr, bound, rows);
   DMH_CHECK_LAUNCH("dmh_gn_finalize_bound");
   return DMH_OK;
 }
@@ -214,27 +225,27 @@ extern "C" int dmh_gn_finalize_train(const float* stats, int tiles, const float*
   DMH_REQUIRE(stats && gamma && beta && coef && mr, "dmh_gn_finalize_train: null pointer");
   DMH_REQUIRE(B > 0 && C > 0 && groups > 0 && C % groups == 0 && tiles > 0 && hw > 0, "dmh_gn_finalize_train: bad shape");
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(256), 0, (hipStream_t)stream, stats, tiles, gamma, beta,
-                     ss, ss_stride, coef, C, groups, hw, eps, mr, (float*)nullptr);
+                     ss, ss_stride, coef, C, groups, hw, eps, mr, (float*)nullptr, (const int32_t*)nullptr);
   DMH_CHECK_LAUNCH("dmh_gn_finalize_train");
   return DMH_OK;
 }
 
 extern "C" int dmh_gn_silu_residual(const float* y, const float* coef, const float* res, float* out, int B, int HW,
-                                    int C, void* stream) {
+                                    int C, const int32_t* rows, void* stream) {
   DMH_REQUIRE(y && coef && out, "dmh_gn_silu_residual: null pointer");
   DMH_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 4 == 0, "dmh_gn_silu_residual: bad shape (C %% 4 != 0?)");
   const int64_t per_sample4 = (int64_t)HW * C / 4;
   const int64_t total4 = per_sample4 * B;
   const unsigned grid = (unsigned)(cdiv64(total4, 256) < 8192 ? cdiv64(total4, 256) : 8192);
   hipLaunchKernelGGL(gn_silu_residual_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, y, coef, res, out,
-                     per_sample4, C, total4, (float*)nullptr, 0.f);
+                     per_sample4, C, total4, (float*)nullptr, 0.f, rows);
   DMH_CHECK_LAUNCH("dmh_gn_silu_residual");
   return DMH_OK;
 }
 
 // same + pstats [B*HW][2] = (mean, rstd) over the channels of every output pixel, as dmh_pixel_stats(out) would give
 extern "C" int dmh_gn_silu_residual_stats(const float* y, const float* coef, const float* res, float* out, float* pstats,
-                                          int B, int HW, int C, float eps, void* stream) {
+                                          int B, int HW, int C, float eps, const int32_t* rows, void* stream) {
   DMH_REQUIRE(y && coef && out && pstats, "dmh_gn_silu_residual_stats: null pointer");
   DMH_REQUIRE(B > 0 && HW > 0 && (C == 64 || C == 128 || C == 256),
               "dmh_gn_silu_residual_stats: C must be 64, 128 or 256 (got %d)", C);
@@ -244,24 +255,24 @@ extern "C" int dmh_gn_silu_residual_stats(const float* y, const float* coef, con
   hipStream_t st = (hipStream_t)stream;
   if (C == 64)
     hipLaunchKernelGGL(gn_silu_residual_kernel<16>, dim3(grid), dim3(256), 0, st, y, coef, res, out, per_sample4, C, total4,
-                       pstats, eps);
+                       pstats, eps, rows);
   else if (C == 128)
     hipLaunchKernelGGL(gn_silu_residual_kernel<32>, dim3(grid), dim3(256), 0, st, y, coef, res, out, per_sample4, C, total4,
-                       pstats, eps);
+                       pstats, eps, rows);
   else
     hipLaunchKernelGGL(gn_silu_residual_kernel<64>, dim3(grid), dim3(256), 0, st, y, coef, res, out, per_sample4, C, total4,
-                       pstats, eps);
+                       pstats, eps, rows);
   DMH_CHECK_LAUNCH("dmh_gn_silu_residual_stats");
   return DMH_OK;
 }
 
 template <int LPP, int NV>
 static int launch_ln(const float* x, const float* g, const float* res, float* out, int64_t npix, int C, float eps,
-                     hipStream_t st) {
+                     const int32_t* rows, int64_t ppr, hipStream_t st) {
   const int64_t ppb = 256 / LPP;
   const int64_t need = cdiv64(npix, ppb);
   const unsigned grid = (unsigned)(need < 16384 ? need : 16384);
-  hipLaunchKernelGGL((chan_layernorm_kernel<LPP, NV>), dim3(grid), dim3(256), 0, st, x, g, res, out, npix, C, eps);
+  hipLaunchKernelGGL((chan_layernorm_kernel<LPP, NV>), dim3(grid), dim3(256), 0, st, x, g, res, out, npix, C, eps, rows, ppr);
   DMH_CHECK_LAUNCH("dmh_chan_layernorm");
   return DMH_OK;
 }
@@ -270,12 +281,15 @@ static int launch_ln(const float* x, const float* g, const float* res, float* ou
 // same two-pass arithmetic as chan_layernorm_kernel
 template <int LPP, int NV>
 __global__ __launch_bounds__(256) void pixel_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
-                                                          int64_t npix, int C, float eps) {
+                                                          int64_t npix_all, int C, float eps,
+                                                          const int32_t* __restrict__ rows, int64_t pix_per_row) {
   const int C4 = C >> 2;
   const int sub = threadIdx.x % LPP;
   const int64_t pix_per_block = 256 / LPP;
-  for (int64_t pix = (int64_t)blockIdx.x * pix_per_block + threadIdx.x / LPP; pix < npix;
-       pix += (int64_t)gridDim.x * pix_per_block) {
+  const int64_t npix = rows ? pix_per_row * rows[0] : npix_all;   // (a row subset, common.h)
+  for (int64_t pl = (int64_t)blockIdx.x * pix_per_block + threadIdx.x / LPP; pl < npix;
+       pl += (int64_t)gridDim.x * pix_per_block) {
+    const int64_t pix = rows ? (int64_t)rows[1 + pl / pix_per_row] * pix_per_row + pl % pix_per_row : pl;
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
@@ -305,42 +319,46 @@ __global__ __launch_bounds__(256) void pixel_stats_kernel(const float* __restric
 }
 
 template <int LPP, int NV>
-static int launch_ps(const float* x, float* stats, int64_t npix, int C, float eps, hipStream_t st) {
+static int launch_ps(const float* x, float* stats, int64_t npix, int C, float eps, const int32_t* rows, int64_t ppr,
+                     hipStream_t st) {
   const int64_t ppb = 256 / LPP;
   const int64_t need = cdiv64(npix, ppb);
   const unsigned grid = (unsigned)(need < 16384 ? need : 16384);
-  hipLaunchKernelGGL((pixel_stats_kernel<LPP, NV>), dim3(grid), dim3(256), 0, st, x, stats, npix, C, eps);
+  hipLaunchKernelGGL((pixel_stats_kernel<LPP, NV>), dim3(grid), dim3(256), 0, st, x, stats, npix, C, eps, rows, ppr);
   DMH_CHECK_LAUNCH("dmh_pixel_stats");
   return DMH_OK;
 }
 
-extern "C" int dmh_pixel_stats(const float* x, float* stats, int64_t npix, int C, float eps, void* stream) {
+extern "C" int dmh_pixel_stats(const float* x, float* stats, int64_t npix, int C, float eps, const int32_t* rows,
+                               int64_t pix_per_row, void* stream) {
   DMH_REQUIRE(x && stats, "dmh_pixel_stats: null pointer");
+  DMH_REQUIRE(!rows || (pix_per_row > 0 && npix % pix_per_row == 0), "dmh_pixel_stats: rows needs pix_per_row dividing npix");
   DMH_REQUIRE(npix > 0 && C > 0 && C % 4 == 0 && C <= 2048, "dmh_pixel_stats: unsupported C=%d", C);
   hipStream_t st = (hipStream_t)stream;
   const int C4 = C / 4;
-  if (C4 <= 8) return launch_ps<8, 1>(x, stats, npix, C, eps, st);
-  if (C4 <= 16) return launch_ps<16, 1>(x, stats, npix, C, eps, st);
-  if (C4 <= 32) return launch_ps<32, 1>(x, stats, npix, C, eps, st);
-  if (C4 <= 64) return launch_ps<64, 1>(x, stats, npix, C, eps, st);
-  if (C4 <= 128) return launch_ps<64, 2>(x, stats, npix, C, eps, st);
-  if (C4 <= 256) return launch_ps<64, 4>(x, stats, npix, C, eps, st);
-  return launch_ps<64, 8>(x, stats, npix, C, eps, st);
+  if (C4 <= 8) return launch_ps<8, 1>(x, stats, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 16) return launch_ps<16, 1>(x, stats, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 32) return launch_ps<32, 1>(x, stats, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 64) return launch_ps<64, 1>(x, stats, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 128) return launch_ps<64, 2>(x, stats, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 256) return launch_ps<64, 4>(x, stats, npix, C, eps, rows, pix_per_row, st);
+  return launch_ps<64, 8>(x, stats, npix, C, eps, rows, pix_per_row, st);
 }
 
 extern "C" int dmh_chan_layernorm(const float* x, const float* g, const float* res, float* out, int64_t npix, int C,
-                                  float eps, void* stream) {
+                                  float eps, const int32_t* rows, int64_t pix_per_row, void* stream) {
   DMH_REQUIRE(x && g && out, "dmh_chan_layernorm: null pointer");
+  DMH_REQUIRE(!rows || (pix_per_row > 0 && npix % pix_per_row == 0), "dmh_chan_layernorm: rows needs pix_per_row dividing npix");
   DMH_REQUIRE(npix > 0 && C > 0 && C % 4 == 0 && C <= 2048, "dmh_chan_layernorm: unsupported C=%d", C);
   hipStream_t st = (hipStream_t)stream;
   const int C4 = C / 4;
-  if (C4 <= 2) return launch_ln<2, 1>(x, g, res, out, npix, C, eps, st);
-  if (C4 <= 4) return launch_ln<4, 1>(x, g, res, out, npix, C, eps, st);
-  if (C4 <= 8) return launch_ln<8, 1>(x, g, res, out, npix, C, eps, st);
-  if (C4 <= 16) return launch_ln<16, 1>(x, g, res, out, npix, C, eps, st);
-  if (C4 <= 32) return launch_ln<32, 1>(x, g, res, out, npix, C, eps, st);
-  if (C4 <= 64) return launch_ln<64, 1>(x, g, res, out, npix, C, eps, st);
-  if (C4 <= 128) return launch_ln<64, 2>(x, g, res, out, npix, C, eps, st);
-  if (C4 <= 256) return launch_ln<64, 4>(x, g, res, out, npix, C, eps, st);
-  return launch_ln<64, 8>(x, g, res, out, npix, C, eps, st);
+  if (C4 <= 2) return launch_ln<2, 1>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 4) return launch_ln<4, 1>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 8) return launch_ln<8, 1>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 16) return launch_ln<16, 1>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 32) return launch_ln<32, 1>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 64) return launch_ln<64, 1>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 128) return launch_ln<64, 2>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  if (C4 <= 256) return launch_ln<64, 4>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
+  return launch_ln<64, 8>(x, g, res, out, npix, C, eps, rows, pix_per_row, st);
 }

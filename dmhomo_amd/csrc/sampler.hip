@@ -132,12 +132,17 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(DmhStep s, const floa
                                                            const float* __restrict__ mn, const float* __restrict__ x,
                                                            const float* __restrict__ noise, float* __restrict__ img_out,
                                                            float* __restrict__ x_start, float* __restrict__ pred_noise,
-                                                           int64_t n) {
+                                                           int64_t n, const uint8_t* __restrict__ keep, int64_t per_row) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float mo = mc[i];
+    float mo;
     if (mn) {
+      // keep (with model_null): row i / per_row of model_cond was only computed where keep != 0 — a row whose class the
+      // conditional pass dropped (CFG:415-425) has the null pass's inputs, so its logits ARE the null logits
       const float nl = mn[i];
+      mo = (keep && !keep[i / per_row]) ? nl : mc[i];
       mo = nl + (mo - nl) * s.cond_scale;  // CFG:410
+    } else {
+      mo = mc[i];
     }
     const float xt = x[i];
     float x0, pn;
@@ -175,13 +180,16 @@ __global__ __launch_bounds__(256) void sampler_step_dev_kernel(const DmhStep* __
                                                                const float* __restrict__ mn, const float* x,
                                                                const float* __restrict__ noise, float* img_out,
                                                                float* __restrict__ x_start, float* __restrict__ pred_noise,
-                                                               int64_t n) {
+                                                               int64_t n, const uint8_t* __restrict__ keep, int64_t per_row) {
   const DmhStep s = *sp;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    float mo = mc[i];
+    float mo;
     if (mn) {
       const float nl = mn[i];
+      mo = (keep && !keep[i / per_row]) ? nl : mc[i];   // (as sampler_step_kernel)
       mo = nl + (mo - nl) * s.cond_scale;  // CFG:410
+    } else {
+      mo = mc[i];
     }
     const float xt = x[i];
     float x0, pn;
@@ -369,23 +377,48 @@ extern "C" int dmh_final_conv_nchw(const float* x, const float* w, const float* 
 
 extern "C" int dmh_sampler_step(const DmhStep* s, const float* model_cond, const float* model_null, const float* x,
                                 const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
-                                void* stream) {
+                                const uint8_t* keep, int64_t per_row, void* stream) {
   DMH_REQUIRE(s && model_cond && x && img_out && n > 0, "dmh_sampler_step: bad arguments");
+  DMH_REQUIRE(!keep || (model_null && per_row > 0 && n % per_row == 0), "dmh_sampler_step: keep needs model_null and per_row dividing n");
   DMH_REQUIRE(s->objective >= 0 && s->objective <= 2 && s->mode >= 0 && s->mode <= 2, "dmh_sampler_step: bad enum");
   DMH_REQUIRE(s->mode != 0 || noise, "dmh_sampler_step: DDIM update needs noise");
   hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, *s, model_cond,
-                     model_null, x, noise, img_out, x_start, pred_noise, n);
+                     model_null, x, noise, img_out, x_start, pred_noise, n, keep, per_row);
   DMH_CHECK_LAUNCH("dmh_sampler_step");
   return DMH_OK;
 }
 
 extern "C" int dmh_sampler_step_dev(const DmhStep* cur_dev, const float* model_cond, const float* model_null, const float* x,
                                     const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
-                                    void* stream) {
+                                    const uint8_t* keep, int64_t per_row, void* stream) {
   DMH_REQUIRE(cur_dev && model_cond && x && img_out && n > 0, "dmh_sampler_step_dev: bad arguments");
+  DMH_REQUIRE(!keep || (model_null && per_row > 0 && n % per_row == 0), "dmh_sampler_step_dev: keep needs model_null and per_row dividing n");
   hipLaunchKernelGGL(sampler_step_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, cur_dev, model_cond,
-                     model_null, x, noise, img_out, x_start, pred_noise, n);
+                     model_null, x, noise, img_out, x_start, pred_noise, n, keep, per_row);
   DMH_CHECK_LAUNCH("dmh_sampler_step_dev");
+  return DMH_OK;
+}
+
+// rows[0] = n, rows[1 ..] = the rows b < B with keep[b] != 0 in ascending order, then B .. B + extra - 1: the active-row
+// subset of a classifier-free-guidance pass (common.h: dmh_rows_n / dmh_rows_phys).  One wave.
+__global__ __launch_bounds__(64) void rows_from_keep_kernel(const uint8_t* __restrict__ keep, int B, int extra,
+                                                            int32_t* __restrict__ rows) {
+  int n = 0;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + (int)threadIdx.x;
+    const bool k = b < B && keep[b] != 0;
+    const unsigned long long m = __ballot(k);
+    if (k) rows[1 + n + __popcll(m & ((1ull << threadIdx.x) - 1ull))] = b;
+    n += __popcll(m);
+  }
+  for (int j = threadIdx.x; j < extra; j += 64) rows[1 + n + j] = B + j;
+  if (threadIdx.x == 0) rows[0] = n + extra;
+}
+
+extern "C" int dmh_rows_from_keep(const uint8_t* keep, int B, int extra, int32_t* rows, void* stream) {
+  DMH_REQUIRE(keep && rows && B > 0 && extra >= 0, "dmh_rows_from_keep: bad arguments");
+  hipLaunchKernelGGL(rows_from_keep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, keep, B, extra, rows);
+  DMH_CHECK_LAUNCH("dmh_rows_from_keep");
   return DMH_OK;
 }
 

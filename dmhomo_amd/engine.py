@@ -46,6 +46,7 @@ class UnetEngine:
         self.module = module
         self.groups = groups
         self._sig = None
+        self._rows = None      # the active-row list of the trunk pass being launched (ops.rows_from_keep), or None
 
     # ------------------------------------------------------------------ weights
     def _signature(self):
@@ -192,46 +193,48 @@ class UnetEngine:
         launch, which also applies the UNet's final 1x1 projection to every finished pixel -> (x or None, y NCHW)."""
         B, H, W, _ = x0.shape
         hw = H * W
-        y1, st1 = pre if pre is not None else ops.conv2d(r.conv1, x0, x1, want_stats=True)
+        rows = self._rows
+        y1, st1 = pre if pre is not None else ops.conv2d(r.conv1, x0, x1, want_stats=True, rows=rows)
         ss = ss_all[:, r.ss_off:r.ss_off + 2 * r.cout]
         if ops.STATIC_BOUND:
-            coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss, want_bound=True)
+            coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss, want_bound=True, rows=rows)
         else:
-            coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss), None
-        y2, st2 = ops.conv2d(r.conv2, y1, in_coef=coef1, want_stats=True, in_bound=bound1)
-        coef2 = ops.gn_finalize(st2, r.g2, r.b2, hw, self.groups)
+            coef1, bound1 = ops.gn_finalize(st1, r.g1, r.b1, hw, self.groups, ss, rows=rows), None
+        y2, st2 = ops.conv2d(r.conv2, y1, in_coef=coef1, want_stats=True, in_bound=bound1, rows=rows)
+        coef2 = ops.gn_finalize(st2, r.g2, r.b2, hw, self.groups, rows=rows)
         if final is not None:
-            return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, final=final, keep_out=keep_out, fin_out=fin_out)
+            return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, final=final, keep_out=keep_out, fin_out=fin_out, rows=rows)
         if r.res is not None:
             if pixel_stats and r.cout == 64 and r.res.k == 1 and 64 in ops.PIXEL_STATS_FUSABLE and ops.f16x3_default() \
                     and os.environ.get('DMH_CONV_PIXEL_STATS', '1') != '0':      # (knob: same-box A/Bs)
                 # (the up path at dim 64: the LayerNorm statistics of the LinearAttention behind this block come out of the
                 #  res_conv launch that finishes it — DmhConv.pix_stats — instead of a dmh_pixel_stats pass over its output)
-                return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, pixel_stats=True)
-            x = ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2)
+                return ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, pixel_stats=True, rows=rows)
+            x = ops.conv2d(r.res, x0, x1, res=y2, res_coef=coef2, rows=rows)
             return (x, None) if pixel_stats else x
         assert x1 is None
         if pixel_stats:
             if r.cout in ops.PIXEL_STATS_FUSABLE:
-                return ops.gn_silu_residual(y2, coef2, x0, pixel_stats=True)
-            return ops.gn_silu_residual(y2, coef2, x0), None
-        return ops.gn_silu_residual(y2, coef2, x0)
+                return ops.gn_silu_residual(y2, coef2, x0, pixel_stats=True, rows=rows)
+            return ops.gn_silu_residual(y2, coef2, x0, rows=rows), None
+        return ops.gn_silu_residual(y2, coef2, x0, rows=rows)
 
     def _attn(self, a, x, stats=None):
+        rows = self._rows
         if a.plo is not None:
-            return ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, out=a.plo, stats=stats)
+            return ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, out=a.plo, stats=stats, rows=rows)
         if a.pla is not None:
-            o = ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, stats=stats)
-            y = ops.conv2d(a.out, o)
-            return ops.chan_layernorm(y, a.out_g, res=x)
-        xn = ops.chan_layernorm(x, a.ln_g)
-        qkv = ops.conv2d(a.qkv, xn)
+            o = ops.linear_attention_fused(x, a.ln_g, a.pla, ATTN_SCALE, stats=stats, rows=rows)
+            y = ops.conv2d(a.out, o, rows=rows)
+            return ops.chan_layernorm(y, a.out_g, res=x, rows=rows)
+        xn = ops.chan_layernorm(x, a.ln_g, rows=rows)
+        qkv = ops.conv2d(a.qkv, xn, rows=rows)
         if a.linear:
-            o = ops.linear_attention_core(qkv, ATTN_SCALE)
-            y = ops.conv2d(a.out, o)
-            return ops.chan_layernorm(y, a.out_g, res=x)
-        o = ops.attention_core(qkv, ATTN_SCALE)
-        return ops.conv2d(a.out, o, res=x)
+            o = ops.linear_attention_core(qkv, ATTN_SCALE, rows=rows)
+            y = ops.conv2d(a.out, o, rows=rows)
+            return ops.chan_layernorm(y, a.out_g, res=x, rows=rows)
+        o = ops.attention_core(qkv, ATTN_SCALE, rows=rows)
+        return ops.conv2d(a.out, o, res=x, rows=rows)
 
     # ------------------------------------------------------------------ program
     def embed(self, time, class_rows, reps):
@@ -285,14 +288,24 @@ class UnetEngine:
         self.ensure_prepared()
         return ops.conv2d(self.downs[0][0].conv1, x0, None, want_stats=True)
 
-    def trunk(self, x0, cond, taps=None, first=None, out=None, ss_all=None):
+    def trunk(self, x0, cond, taps=None, first=None, out=None, ss_all=None, rows=None):
         """everything after init_conv.  x0: stem() output with one row per row of ``cond``.
         first: ``first_conv(x0)`` when the caller has it already (shared between the CFG passes).
         out: a contiguous (rows, out_dim, H, W) tensor that receives the result (a row slice of the caller's buffer).
         ss_all: the (scale, shift) rows when the caller has them already (``ss_tables`` + ``ops.ss_gather``); ``cond`` is then unused.
+        rows: the active-row list of this pass (``ops.rows_from_keep``): every launch works on the listed rows of its tensors
+        only — the other rows of every intermediate and of the result stay unwritten (Unet.dedup_dropped_rows).
         ``taps`` (dict) optionally receives the NHWC activation after each stage member, keyed like the
         reference's module names ('downs.0.0', 'mid_attn', ...): per-layer parity tests."""
         self.ensure_prepared()
+        self._rows = rows
+        try:
+            return self._trunk(x0, cond, taps, first, out, ss_all)
+        finally:
+            self._rows = None
+
+    def _trunk(self, x0, cond, taps, first, out, ss_all):
+        rows = self._rows
 
         def tap(name, v):
             if taps is not None:
@@ -311,7 +324,7 @@ class UnetEngine:
             tap(f'downs.{i}.1', x)
             x = tap(f'downs.{i}.2', self._attn(at, x, pst))
             hs.append(x)
-            x = tap(f'downs.{i}.3', ops.conv2d(down, x))
+            x = tap(f'downs.{i}.3', ops.conv2d(down, x, rows=rows))
         x = tap('mid_block1', self._res(self.mid1, x, None, ss_all))
         x = tap('mid_attn', self._attn(self.mid_attn, x))
         x = tap('mid_block2', self._res(self.mid2, x, None, ss_all))
@@ -321,7 +334,7 @@ class UnetEngine:
                 (self._res(b2, x, hs.pop(), ss_all), None)
             tap(f'ups.{i}.1', x)
             x = tap(f'ups.{i}.2', self._attn(at, x, pst))
-            x = tap(f'ups.{i}.3', ops.conv2d(up, x))
+            x = tap(f'ups.{i}.3', ops.conv2d(up, x, rows=rows))
         fr = self.final_res
         if FUSED_FINAL and fr.res is not None and fr.res.k == 1 and fr.cout <= 64 and self.final_w.shape[0] <= 8 \
                 and ops.f16x3_default():

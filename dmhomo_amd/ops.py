@@ -120,8 +120,21 @@ def conv_out_hw(pc, h, w):
 CONV_LOG = None
 
 
+def rows_from_keep(keep, extra=0):
+    """the active-row list of a classifier-free-guidance pass (include/dmhomo_hip.h, "Row subsets"): int32 (1 + B + extra,)
+    = [n, the rows with keep != 0 ..., B .. B + extra - 1, (unused)]; every batched wrapper below takes it as ``rows=``."""
+    B = keep.shape[0]
+    rows = torch.empty((1 + B + extra,), device=keep.device, dtype=torch.int32)
+    call('dmh_rows_from_keep', ptr(keep, torch.uint8), B, int(extra), ptr(rows, torch.int32))
+    return rows
+
+
+def _rows(rows):
+    return ptr(rows, torch.int32)
+
+
 def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stats=False, in_bound=None, final=None,
-           keep_out=True, pixel_stats=False, eps=1e-5, fin_out=None):
+           keep_out=True, pixel_stats=False, eps=1e-5, fin_out=None, rows=None):
     """K1/K2.  src0 (B,H,W,C0) [+ src1 (B,H,W,C1) = fused channel concat]. Returns out or (out, stats).
     in_bound (B, k), with in_coef: upper bounds of the prologue's |a*x+b| per sample (gn_finalize(want_bound=True)).
     final = (w (n, Cout), b (n,) or None), 1x1 convs with Cout <= 64 only: also apply that pointwise projection to every
@@ -159,7 +172,7 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
     d = _lib.DmhConv(C.sizeof(_lib.DmhConv), ptr(src0), ptr(src1), ptr(pc.wpack), ptr(pc.bias), ptr(in_coef), ptr(res), ptr(res_coef),
                      ptr(out), ptr(stats), B, H, W, pc.c0, pc.c1, pc.cout, pc.k, pc.k, pc.stride, pc.upsample2,
                      ptr(in_bound), 0 if in_bound is None else in_bound.shape[1],
-                     0 if fin_w is None else fin_w.shape[0], ptr(fin_w), ptr(fin_b), ptr(fin_out), ptr(pst), float(eps))
+                     0 if fin_w is None else fin_w.shape[0], ptr(fin_w), ptr(fin_b), ptr(fin_out), ptr(pst), float(eps), _rows(rows))
     if CONV_LOG is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -181,7 +194,7 @@ def conv2d(pc, src0, src1=None, in_coef=None, res=None, res_coef=None, want_stat
 STATIC_BOUND = os.environ.get('DMH_CONV_STATIC_BOUND', '1') != '0'
 
 
-def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5, want_bound=False):
+def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5, want_bound=False, rows=None):
     """N2: stats (B,tiles,C,2) -> coef (B,2,C).  ss: (B, >=2C) view whose row b starts with (scale[C], shift[C]).
     want_bound: -> (coef, bound) with bound (B, groups) >= |a*x + b| over each (sample, group): ``conv2d(in_bound=)``."""
     B, tiles, Cc, _ = stats.shape
@@ -193,10 +206,10 @@ def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5, want_bound=Fa
     if want_bound:
         bound = _empty((B, groups), stats)
         call('dmh_gn_finalize_bound', ptr(stats), tiles, ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(coef), ptr(bound),
-             B, Cc, groups, hw, float(eps))
+             B, Cc, groups, hw, float(eps), _rows(rows))
         return coef, bound
     call('dmh_gn_finalize', ptr(stats), tiles, ptr(gamma), ptr(beta), ss_ptr, ss_stride, ptr(coef), B, Cc, groups,
-         hw, float(eps))
+         hw, float(eps), _rows(rows))
     return coef
 
 
@@ -205,29 +218,31 @@ def gn_finalize(stats, gamma, beta, hw, groups, ss=None, eps=1e-5, want_bound=Fa
 PIXEL_STATS_FUSABLE = () if os.environ.get('DMH_FUSED_PIXEL_STATS') == '0' else (64, 128, 256)
 
 
-def gn_silu_residual(y, coef, res, pixel_stats=False, eps=1e-5):
+def gn_silu_residual(y, coef, res, pixel_stats=False, eps=1e-5, rows=None):
     """SiLU(a*y+b) + res.  pixel_stats: also return the (B, H*W, 2) per-pixel (mean, rstd) of the channel LayerNorm of the
     result — what ``dmh_pixel_stats`` would compute from it — for ``linear_attention_fused(..., stats=)``."""
     B, H, W, Cc = y.shape
     out = torch.empty_like(y)
     if pixel_stats:
         stats = _empty((B, H * W, 2), y)
-        call('dmh_gn_silu_residual_stats', ptr(y), ptr(coef), ptr(res), ptr(out), ptr(stats), B, H * W, Cc, float(eps))
+        call('dmh_gn_silu_residual_stats', ptr(y), ptr(coef), ptr(res), ptr(out), ptr(stats), B, H * W, Cc, float(eps),
+             _rows(rows))
         return out, stats
-    call('dmh_gn_silu_residual', ptr(y), ptr(coef), ptr(res), ptr(out), B, H * W, Cc)
+    call('dmh_gn_silu_residual', ptr(y), ptr(coef), ptr(res), ptr(out), B, H * W, Cc, _rows(rows))
     return out
 
 
-def chan_layernorm(x, g, res=None, eps=1e-5):
+def chan_layernorm(x, g, res=None, eps=1e-5, rows=None):
     """N4 (+ optional residual add)."""
     Cc = x.shape[-1]
     out = torch.empty_like(x)
-    call('dmh_chan_layernorm', ptr(x), ptr(g), ptr(res), ptr(out), x.numel() // Cc, Cc, float(eps))
+    npix = x.numel() // Cc
+    call('dmh_chan_layernorm', ptr(x), ptr(g), ptr(res), ptr(out), npix, Cc, float(eps), _rows(rows), npix // x.shape[0])
     return out
 
 
 # ------------------------------------------------------------------ attention cores
-def linear_attention_core(qkv, scale):
+def linear_attention_core(qkv, scale, rows=None):
     """K3.  qkv (B,H,W,384) -> (B,H,W,128)."""
     B, H, W, c = qkv.shape
     assert c == 384
@@ -235,9 +250,9 @@ def linear_attention_core(qkv, scale):
     partial = _empty((lib().dmh_linattn_partial_floats(B, n),), qkv)
     ctx = _empty((B, 4, 32, 32), qkv)
     out = _empty((B, H, W, 128), qkv)
-    call('dmh_linattn_context', ptr(qkv), ptr(partial), B, n)
-    call('dmh_linattn_merge', ptr(partial), ptr(ctx), B, n)
-    call('dmh_linattn_apply', ptr(qkv), ptr(ctx), ptr(out), B, n, float(scale))
+    call('dmh_linattn_context', ptr(qkv), ptr(partial), B, n, _rows(rows))
+    call('dmh_linattn_merge', ptr(partial), ptr(ctx), B, n, _rows(rows))
+    call('dmh_linattn_apply', ptr(qkv), ptr(ctx), ptr(out), B, n, float(scale), _rows(rows))
     return out
 
 
@@ -266,7 +281,7 @@ class PackedLinAttnOut:
         self.ln_g = ln_g.detach().reshape(-1).contiguous().float()
 
 
-def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None):
+def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None, rows=None):
     """K3f.  x (B,H,W,C) -> attention core output (B,H,W,128) of LinearAttention(PreNorm-LayerNorm(x)): LayerNorm,
     to_qkv and both attention passes in two kernels, q/k/v never stored.
     With ``out`` (PackedLinAttnOut, C == 64) the second pass also applies to_out, its LayerNorm and the residual:
@@ -276,30 +291,30 @@ def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None):
     n = H * W
     if stats is None:     # (the producer of x may have written them already: gn_silu_residual(pixel_stats=True))
         stats = _empty((B, n, 2), x)
-        call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, c, float(eps))
+        call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, c, float(eps), _rows(rows), n)
     assert stats.shape == (B, n, 2)
     ns = lib().dmh_linattn_fused_splits(B, n)
     partial = _empty((B, ns, 4, 1088), x)
     ctx = _empty((B, 4, 32, 32), x)
-    call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c)
-    call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
+    call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c, _rows(rows))
+    call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns, _rows(rows))
     if out is not None:
         y = _empty((B, H, W, 64), x)
         call('dmh_linattn_fused_apply_out', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(out.wpack),
-             ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps))
+             ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps), _rows(rows))
         return y
     o = _empty((B, H, W, 128), x)
     call('dmh_linattn_fused_apply', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(o), B, n, c,
-         float(scale))
+         float(scale), _rows(rows))
     return o
 
 
-def attention_core(qkv, scale):
+def attention_core(qkv, scale, rows=None):
     """K4.  qkv (B,H,W,384) -> (B,H,W,128)."""
     B, H, W, c = qkv.shape
     assert c == 384
     out = _empty((B, H, W, 128), qkv)
-    call('dmh_attention', ptr(qkv), ptr(out), B, H * W, float(scale))
+    call('dmh_attention', ptr(qkv), ptr(out), B, H * W, float(scale), _rows(rows))
     return out
 
 
@@ -371,12 +386,14 @@ OBJECTIVE = {'pred_noise': 0, 'pred_x0': 1, 'pred_v': 2}
 MODE_DDIM, MODE_LAST, MODE_DDPM = 0, 1, 2
 
 
-def sampler_step(step, model_cond, model_null, x, noise, want_x_start=True, want_pred_noise=False):
+def sampler_step(step, model_cond, model_null, x, noise, want_x_start=True, want_pred_noise=False, keep=None):
+    """keep (B,) uint8, with model_null: rows with keep == 0 take model_null as their conditional logits (rows the conditional
+    pass did not compute: Unet.dedup_dropped_rows)"""
     img = torch.empty_like(x)
     xs = torch.empty_like(x) if want_x_start else None
     pn = torch.empty_like(x) if want_pred_noise else None
     call('dmh_sampler_step', C.byref(step), ptr(model_cond), ptr(model_null), ptr(x), ptr(noise), ptr(img), ptr(xs),
-         ptr(pn), x.numel())
+         ptr(pn), x.numel(), ptr(keep, torch.uint8), x.numel() // x.shape[0])
     return img, xs, pn
 
 
@@ -408,11 +425,11 @@ def sampler_seek(cursor, k, table, times, cur, tcond):
          times.shape[0], ptr(cur, torch.uint8), ptr(tcond, torch.int64), tcond.shape[0])
 
 
-def sampler_step_dev(cur, model_cond, model_null, x, noise, out=None):
+def sampler_step_dev(cur, model_cond, model_null, x, noise, out=None, keep=None):
     """sampler_step with its DmhStep in device memory (``cur`` of step_table); out may be x (in place)."""
     img = torch.empty_like(x) if out is None else out
     call('dmh_sampler_step_dev', ptr(cur, torch.uint8), ptr(model_cond), ptr(model_null), ptr(x), ptr(noise), ptr(img),
-         None, None, x.numel())
+         None, None, x.numel(), ptr(keep, torch.uint8), x.numel() // x.shape[0])
     return img
 
 
@@ -688,9 +705,9 @@ def linear_attention_core_train(qkv, scale):
     ctx = _empty((B, 4, 32, 32), qkv)
     ms = _empty((B, 4, 32, 2), qkv)
     out = _empty((B, H, W, 128), qkv)
-    call('dmh_linattn_context', ptr(qkv), ptr(partial), B, n)
+    call('dmh_linattn_context', ptr(qkv), ptr(partial), B, n, None)
     call('dmh_linattn_merge_ms', ptr(partial), ptr(ctx), ptr(ms), B, n)
-    call('dmh_linattn_apply', ptr(qkv), ptr(ctx), ptr(out), B, n, float(scale))
+    call('dmh_linattn_apply', ptr(qkv), ptr(ctx), ptr(out), B, n, float(scale), None)
     return out, dict(qkv=qkv, ctx=ctx, ms=ms, scale=float(scale))
 
 

@@ -36,7 +36,7 @@ extern "C" {
 const char* dmh_last_error(void);
 /* DMH_ABI_VERSION of the library: bumped whenever a struct layout or an entry point changes; a binding must refuse a
  * library whose version differs from the header it was written against (dmhomo_amd/_lib.py does). */
-#define DMH_ABI_VERSION 400
+#define DMH_ABI_VERSION 500
 int dmh_version(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -87,6 +87,23 @@ int64_t dmh_conv_up2_pack_floats(int Cout, int C0);
 int dmh_pack_conv_weight_up2(const float* w_oihw, float* wpack, int Cout, int C0, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Row subsets (round 5): de-duplication of the two classifier-free-guidance passes inside a captured denoise step.
+ * forward_with_cond_scale (CFG:403-410) runs the UNet on the batch twice: once with the class embedding of every row
+ * replaced by the null embedding with probability cond_drop_prob (CFG:415-425 — 0.5 in DGM, also while sampling), once with
+ * all of them replaced.  A row the first pass dropped has exactly the inputs of its row in the second pass, so its logits are
+ * the second pass's logits and need not be computed.  Which rows are kept is DEVICE data (the mask is drawn inside the
+ * captured step), so every batched entry point of the UNet takes an optional `rows`:
+ *     rows == NULL          all B rows of the launch
+ *     rows[0]               n <= B, the number of active rows
+ *     rows[1 + j], j < n    the row (sample slot) logical row j works on
+ * The launch keeps its B-row grid; workgroups of logical rows >= n retire before touching memory, tensors are addressed by
+ * the slot, nothing is gathered or scattered, and the slots that are not listed are neither read nor written.  Rows are
+ * independent of each other in every kernel of the path, so the listed rows come out bit for bit as in the full launch.
+ * dmh_rows_from_keep builds the list: the slots b < B with keep[b] != 0 in ascending order, followed by B .. B+extra-1
+ * (the null pass's rows when both passes share one 2B-row launch); rows: int32 [1 + B + extra], all DEVICE memory. */
+int dmh_rows_from_keep(const uint8_t* keep, int B, int extra, int32_t* rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * K1/K2  convolution as an implicit GEMM.  fp32 tensors in and out; by default the products run on the fp16
  * matrix cores with every fp32 operand carried as block-scaled fp16 pieces (three v_mfma_f32_16x16x32_f16 per
  * product block, fp32 accumulation; error at the level of the fp32 accumulation rounding, fp32 exponent range —
@@ -132,6 +149,8 @@ typedef struct DmhConv {
    * from `out` — for the fused LinearAttention that consumes this launch's output (the up path's res_conv, CFG:241 -> 246). */
   float* pix_stats;
   float pix_eps;
+  /* optional: the active row subset of this launch (see "Row subsets" below); NULL = all B rows */
+  const int32_t* rows;
 } DmhConv;
 
 /* tiles per sample that dmh_conv2d will use for this geometry (size of the stats buffer) */
@@ -147,26 +166,28 @@ int dmh_conv2d(const DmhConv* d, void* stream);
  * stats: [B][tiles][C][2] from dmh_conv2d; ss: NULL or row b at ss + b*ss_stride holds
  * (scale[C], shift[C]) (ResnetBlock mlp output chunk(2), CFG:233-235). Reduction in f64, fixed order. */
 int dmh_gn_finalize(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
-                    int64_t ss_stride, float* coef, int B, int C, int groups, int hw, float eps, void* stream);
+                    int64_t ss_stride, float* coef, int B, int C, int groups, int hw, float eps, const int32_t* rows,
+                    void* stream);
 
 /* dmh_gn_finalize + bound[B][groups]: max over the group's channels of |a| * sqrt(sum x^2) + |b + mean*a| >= |a*x + b|
  * for every element x of the (sample, group) the statistics describe (DmhConv.in_bound) */
 int dmh_gn_finalize_bound(const float* stats, int tiles, const float* gamma, const float* beta, const float* ss,
                           int64_t ss_stride, float* coef, float* bound, int B, int C, int groups, int hw, float eps,
-                          void* stream);
+                          const int32_t* rows, void* stream);
 
 /* out = SiLU(a*y + b) + res   (identity res_conv branch of ResnetBlock, CFG:225,241) */
 int dmh_gn_silu_residual(const float* y, const float* coef, const float* res, float* out, int B, int HW, int C,
-                         void* stream);
+                         const int32_t* rows, void* stream);
 
 /* same, also writing pstats [B*HW][2] = (mean, rstd) of the channel LayerNorm (CFG:137-141) of every output pixel —
  * bitwise what dmh_pixel_stats(out) gives — for a LinearAttention that follows the block (CFG:176-183). C in {64,128,256}. */
 int dmh_gn_silu_residual_stats(const float* y, const float* coef, const float* res, float* out, float* pstats, int B,
-                               int HW, int C, float eps, void* stream);
+                               int HW, int C, float eps, const int32_t* rows, void* stream);
 
-/* N4  channel LayerNorm (biased var, gain only), CFG:137-141, optionally + res (Residual, CFG:103) */
+/* N4  channel LayerNorm (biased var, gain only), CFG:137-141, optionally + res (Residual, CFG:103).
+ * rows (optional row subset) comes with pix_per_row = the pixels of one row, npix = B * pix_per_row. */
 int dmh_chan_layernorm(const float* x, const float* g, const float* res, float* out, int64_t npix, int C,
-                       float eps, void* stream);
+                       float eps, const int32_t* rows, int64_t pix_per_row, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K3  LinearAttention core, CFG:258-269.  qkv: NHWC [B][n][384] = (q|k|v) x 4 heads x 32.
@@ -174,11 +195,12 @@ int dmh_chan_layernorm(const float* x, const float* g, const float* res, float* 
 int dmh_linattn_splits(int n);
 int64_t dmh_linattn_partial_floats(int B, int n);
 /* pass 1: per split of the n pixels, running max / sum of exp / unnormalised k^T v per head */
-int dmh_linattn_context(const float* qkv, float* partial, int B, int n, void* stream);
+int dmh_linattn_context(const float* qkv, float* partial, int B, int n, const int32_t* rows, void* stream);
 /* merge the splits: ctx[b][h][d][e] = softmax_n(k)[d,:] . (v/n)[e,:] */
-int dmh_linattn_merge(const float* partial, float* ctx, int B, int n, void* stream);
+int dmh_linattn_merge(const float* partial, float* ctx, int B, int n, const int32_t* rows, void* stream);
 /* pass 2: out[b][p][h*32+e] = sum_d ctx[d][e] * (softmax_d(q[p]) * scale)[d]; out NHWC [B][n][128] */
-int dmh_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int n, float scale, void* stream);
+int dmh_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int n, float scale, const int32_t* rows,
+                      void* stream);
 
 /* Fused LinearAttention (PreNorm LayerNorm + to_qkv + attention core, CFG:96-103,246-269): q, k, v stay on chip.
  *   stats  = dmh_pixel_stats(x)                         per-pixel (mean, rstd) of the PreNorm LayerNorm, [npix][2]
@@ -187,15 +209,17 @@ int dmh_linattn_apply(const float* qkv, const float* ctx, float* out, int B, int
  *   dmh_linattn_merge_n       -> ctx[B][4][32][32]
  *   dmh_linattn_fused_apply   -> out[B][n][128]         (then to_out conv + LayerNorm + residual as before)
  * x: NHWC [B][n][C], C a multiple of 32. */
-int dmh_pixel_stats(const float* x, float* stats, int64_t npix, int C, float eps, void* stream);
+int dmh_pixel_stats(const float* x, float* stats, int64_t npix, int C, float eps, const int32_t* rows, int64_t pix_per_row,
+                    void* stream);
 int64_t dmh_linattn_fused_pack_floats(int C);
 int dmh_linattn_fused_pack(const float* w_qkv, float* wpack, int C, void* stream);
 int dmh_linattn_fused_splits(int B, int n);
 int dmh_linattn_fused_context(const float* x, const float* stats, const float* ln_g, const float* wpack,
-                              float* partial, int B, int n, int C, void* stream);
-int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, void* stream);
+                              float* partial, int B, int n, int C, const int32_t* rows, void* stream);
+int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, const int32_t* rows, void* stream);
 int dmh_linattn_fused_apply(const float* x, const float* stats, const float* ln_g, const float* wpack,
-                            const float* ctx, float* out, int B, int n, int C, float scale, void* stream);
+                            const float* ctx, float* out, int B, int n, int C, float scale, const int32_t* rows,
+                            void* stream);
 /* C == 64: pass 2 carries the rest of the block too — y[B][n][64] = x + LayerNorm(to_out(attention) + bias) * g
  * (CFG:254-256, 103): the to_out weight [64][128] is packed once by dmh_linattn_out_pack
  * (dmh_linattn_out_pack_floats() floats). */
@@ -203,10 +227,10 @@ int64_t dmh_linattn_out_pack_floats(void);
 int dmh_linattn_out_pack(const float* w_out, float* wpack, void* stream);
 int dmh_linattn_fused_apply_out(const float* x, const float* stats, const float* ln_g, const float* wpack,
                                 const float* ctx, const float* wopack, const float* out_bias, const float* out_ln_g,
-                                float* y, int B, int n, int C, float scale, float eps, void* stream);
+                                float* y, int B, int n, int C, float scale, float eps, const int32_t* rows, void* stream);
 
 /* K4  Attention core, CFG:287-295: softmax_j((q*scale)^T k) v; out NHWC [B][n][128] */
-int dmh_attention(const float* qkv, float* out, int B, int n, float scale, void* stream);
+int dmh_attention(const float* qkv, float* out, int B, int n, float scale, const int32_t* rows, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K5  embeddings / small linears
@@ -248,10 +272,13 @@ typedef struct DmhStep {
   float sqrt_recip_ac, sqrt_recipm1_ac, sqrt_ac, sqrt_1m_ac; /* extract(..., t) CFG:586-601 */
   float c0, c1, c2;   /* DDIM: sqrt(alpha_next), c, sigma (CFG:697-707); DDPM: coef1, coef2, exp(.5 logvar) */
 } DmhStep;
-/* one sampler step on NCHW tensors of n elements: writes img_out and (if non-NULL) x_start, pred_noise */
+/* one sampler step on NCHW tensors of n elements: writes img_out and (if non-NULL) x_start, pred_noise.
+ * keep (optional, with model_null; per_row = elements of one row): uint8 [n / per_row] — rows with keep == 0 were not computed
+ * by the conditional pass (row subsets, above) and take model_null as their conditional logits, which is what CFG:404,409
+ * compute for a row whose class was dropped. */
 int dmh_sampler_step(const DmhStep* s, const float* model_cond, const float* model_null, const float* x,
                      const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
-                     void* stream);
+                     const uint8_t* keep, int64_t per_row, void* stream);
 
 /* The same step with its DmhStep read from DEVICE memory, for a sampling loop (CFG:683-707, DDP:647-735) that replays
  * ONE captured denoise step from a HIP graph: the host fills `table` (one DmhStep per denoise step, host-computed as
@@ -259,7 +286,7 @@ int dmh_sampler_step(const DmhStep* s, const float* model_cond, const float* mod
  * img_out may alias x (the loop's `img = ...` in place); mode and objective are validated when the table is built. */
 int dmh_sampler_step_dev(const DmhStep* cur_dev, const float* model_cond, const float* model_null, const float* x,
                          const float* noise, float* img_out, float* x_start, float* pred_noise, int64_t n,
-                         void* stream);
+                         const uint8_t* keep, int64_t per_row, void* stream);
 /* cursor handling of that loop (one tiny launch): k >= 0: *cursor = k; k < 0: *cursor = min(*cursor + 1, S - 1); then
  * *cur = table[*cursor] and tcond[0 .. B) = times[*cursor] (the `time_cond` tensor of CFG:684 / DDP:700).
  * table: [S] DmhStep, times: [S] int64, cursor: int32, all device memory. */

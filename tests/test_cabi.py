@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in header_functions():
         assert hasattr(h, name), name
     lib = _lib.lib()
-    assert lib.dmh_version() == _lib.ABI_VERSION == 400
+    assert lib.dmh_version() == _lib.ABI_VERSION == 500
 
 
 def test_pure_host_entry_points():
@@ -68,7 +68,7 @@ def test_bad_arguments_use_the_error_channel():
     d = _lib.DmhConv(ctypes.sizeof(_lib.DmhConv))
     assert lib.dmh_conv2d(ctypes.byref(d), None) == -1
     assert b'dmh_conv2d: null pointer' in lib.dmh_last_error()
-    assert lib.dmh_chan_layernorm(None, None, None, None, 4, 64, 1e-5, None) == -1
+    assert lib.dmh_chan_layernorm(None, None, None, None, 4, 64, 1e-5, None, 0, None) == -1
     assert lib.dmh_linear(None, 0, None, None, None, 0, 1, 1, 1, 0, 0, None) == -1
 
 

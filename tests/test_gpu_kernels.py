@@ -179,7 +179,7 @@ def test_conv1x1_fused_final_projection(ops, B, H, W, C0, C1, Co, n):
     if Co == 64:   # DmhConv.pix_stats: the LayerNorm statistics of the output pixels, bitwise dmh_pixel_stats(out)
         out3, pst = ops.conv2d(pc, x0, x1, res=res, res_coef=rcoef, pixel_stats=True)
         want_st = torch.empty((B, H * W, 2), device=dev())
-        ops.call('dmh_pixel_stats', ops.ptr(out), ops.ptr(want_st), B * H * W, Co, 1e-5)
+        ops.call('dmh_pixel_stats', ops.ptr(out), ops.ptr(want_st), B * H * W, Co, 1e-5, None, 0)
         assert torch.equal(out3, out) and torch.equal(pst, want_st)
     with pytest.raises(Exception, match='final projection'):
         ops.conv2d(ops.PackedConv(rand((64, 64, 3, 3), 49, 0.05).to(dev()), None, 64), x0[..., :64].contiguous() if C0 >= 64
@@ -266,7 +266,7 @@ def test_gn_silu_residual_pixel_stats_bitwise(ops, C, H, W, B):
     assert torch.equal(out, plain)
     ref = torch.empty((B, H * W, 2), device=dev())
     from dmhomo_amd._lib import call, ptr
-    call('dmh_pixel_stats', ptr(out), ptr(ref), B * H * W, C, 1e-5)
+    call('dmh_pixel_stats', ptr(out), ptr(ref), B * H * W, C, 1e-5, None, 0)
     assert torch.equal(stats, ref)
     mean = out.reshape(B, H * W, C).double().mean(-1)
     close('pixel mean', stats[..., 0].cpu().double(), mean.cpu(), rtol=1e-5, atol=1e-6)

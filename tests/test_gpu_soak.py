@@ -148,12 +148,12 @@ def test_soak_ring_kernel_beside_a_conv_240_launches(ops, B):
     pla = ops.PackedLinAttn(rand((384, C, 1, 1), 62, C ** -0.5).to(dev()))
     x = (rand((B, H, H, C), 63) * 1.3 + 0.2).to(dev())
     stats = _empty((B, n, 2), x)
-    call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, C, 1e-5)
+    call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, C, 1e-5, None, 0)
     ns = lib().dmh_linattn_fused_splits(B, n)
 
     def context():
         partial = torch.zeros((B, ns, 4, 1088), device=dev())
-        call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(gq), ptr(pla.wpack), ptr(partial), B, n, C)
+        call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(gq), ptr(pla.wpack), ptr(partial), B, n, C, None)
         return partial
     torch.cuda.synchronize()
     alone = context()

@@ -66,7 +66,8 @@ def test_cfg_model_predictions_per_row_timesteps(gd, obj):
     tu = torch.full((3,), 500, device=dev(), dtype=torch.long)
     d.rng = ReplayDeviceRng([gd[f'cfg.mp.{obj}.1.draw']] * 2)
     a = d.model_predictions(x, tu, classes, rf, mk, cond_scale=3., clip_x_start=True)
-    cond, null = d._network(x, tu, classes, rf, mk, 3.)
+    cond, null, computed = d._network(x, tu, classes, rf, mk, 3.)
+    assert computed is None                               # (dedup_dropped_rows is off: every conditional row was computed)
     from dmhomo_amd import ops
     from dmhomo_amd._lib import DmhStep
     blend = DmhStep(objective=1, clip=0, mode=ops.MODE_LAST, cond_scale=3., sqrt_recip_ac=1., sqrt_recipm1_ac=1.)
