@@ -123,10 +123,11 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     'dmh_attention': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p, C.c_void_p]),
     'dmh_sinusoidal_embed': (c_int, [C.c_void_p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
-    'dmh_class_embed': (c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
+    'dmh_class_embed': (c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
     'dmh_linear': (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_int, c_int,
                            C.c_void_p]),
-    'dmh_ss_gather': (c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, c_int, c_f32p, c_int, c_int, C.c_void_p]),
+    'dmh_ss_gather': (c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, c_int, c_f32p, c_int, c_int, c_int,
+                              C.c_void_p]),
     'dmh_assemble_input': (c_int, [c_f32p, c_int, c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
     'dmh_final_conv_nchw': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),

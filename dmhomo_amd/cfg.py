@@ -92,16 +92,24 @@ class DeviceRng:
         else:
             torch.cuda.set_rng_state(snap[1], device)
 
+    def ids_for(self, n):
+        """the sample ids of a draw with n rows: all of them, or — a short last batch of a loader that keeps it, as the
+        reference's DataLoader does (DDP:1746-1752) — the first n (a view: same storage, so a captured graph keyed on the
+        full-size batch is not disturbed)"""
+        n = int(n)
+        if n > self.sample_ids.shape[0]:
+            raise ValueError(f'the generator is keyed for {self.sample_ids.shape[0]} rows, a draw asks for {n}: '
+                             f'key_by_sample with the ids of this batch first')
+        return self.sample_ids if n == self.sample_ids.shape[0] else self.sample_ids[:n]
+
     def randn(self, shape, device):
         if self.keyed:
-            assert int(shape[0]) == self.sample_ids.shape[0], (tuple(shape), self.sample_ids.shape)
-            return ops.rng_indexed(shape, self.sample_ids, self.state, 0)
+            return ops.rng_indexed(shape, self.ids_for(shape[0]), self.state, 0)
         return torch.randn(tuple(shape), device=device)
 
     def uniform(self, n, device):
         if self.keyed:
-            assert int(n) == self.sample_ids.shape[0], (n, self.sample_ids.shape)
-            return ops.rng_indexed((n,), self.sample_ids, self.state, 1)
+            return ops.rng_indexed((n,), self.ids_for(n), self.state, 1)
         return torch.zeros((n,), device=device).float().uniform_(0, 1)
 
 
@@ -147,8 +155,7 @@ class Unet(nn.Module):
         if prob == 0:
             return self._null_mask(batch, device)
         if type(self.rng) is DeviceRng and self.rng.keyed:           # draw + compare + uint8 in one launch
-            assert batch == self.rng.sample_ids.shape[0], (batch, self.rng.sample_ids.shape)
-            return ops.rng_keep_mask(self.rng.sample_ids, self.rng.state, prob)
+            return ops.rng_keep_mask(self.rng.ids_for(batch), self.rng.state, prob)
         return (self.rng.uniform(batch, device) < prob).to(torch.uint8)
 
     def _null_mask(self, batch, device):

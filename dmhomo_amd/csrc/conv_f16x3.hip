@@ -345,13 +345,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
       }
     }
     // block maximum over everything the lanes hold, padding lanes included (their values are real ones from clamped
-    // addresses: the scale only has to bound the tile, and an over-estimate costs nothing — see the header); the padding
-    // itself becomes zero in the split below, which multiplies it by 0 instead of the block scale
+    // addresses, through the prologue like the rest: the scale only has to bound the tile, and an over-estimate costs
+    // nothing — see the header); the padding itself becomes zero in the split below, which multiplies it by 0 instead of the
+    // block scale.  The one exception: a wave that skipped the prologue of the partly filled last load group above holds RAW
+    // pre-GroupNorm values there — all of them padding — and leaves that group out of the maximum under the same uniform
+    // condition (raw activations can be orders of magnitude above SiLU(a*x + b) and would cost the tile its range).
     if (!stat) {
       float mxf = 0.f;
 #pragma unroll
-      for (int i = 0; i < NLOAD; ++i)
+      for (int i = 0; i < NLOAD; ++i) {
+        if (pro && (i + 1) * 256 > IN_PIX * NQ && ((wave_u * 64 + i * 256) >> QS) >= IN_PIX) continue;
         mxf = fmaxf(fmaxf(mxf, fmaxf(fabsf(v[i].x), fabsf(v[i].y))), fmaxf(fabsf(v[i].z), fabsf(v[i].w)));
+      }
       unsigned mx = __float_as_uint(mxf);
       mx = wave_max_u32(mx);
       if (lane == 0) atomicMax(&mxslot[ch & 1], mx);

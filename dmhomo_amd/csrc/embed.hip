@@ -16,12 +16,15 @@ __global__ void sinusoidal_embed_kernel(const int64_t* __restrict__ t, const flo
 // N8: classes_emb(classes) with rows swapped for null_classes_emb where keep == 0 (CFG:419-425)
 __global__ void class_embed_kernel(const int64_t* __restrict__ classes, const uint8_t* __restrict__ keep,
                                    const float* __restrict__ table, const float* __restrict__ null_emb,
-                                   float* __restrict__ out, int R, int dim) {
+                                   float* __restrict__ out, int R, int dim, int num_classes) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= R * dim) return;
   const int r = idx / dim, i = idx % dim;
   const bool k = keep ? (keep[r] != 0) : true;
-  out[idx] = k ? table[(size_t)classes[r] * dim + i] : null_emb[i];
+  const int64_t c = classes[r];
+  // (a class id outside the table is device data the launch cannot refuse — nn.Embedding raises on the host / asserts on the
+  //  device there, CFG:419: the row becomes NaN instead of whatever lies beside the table)
+  out[idx] = k ? ((c >= 0 && c < num_classes) ? table[(size_t)c * dim + i] : __builtin_nanf("")) : null_emb[i];
 }
 
 __device__ __forceinline__ float act_f(float x, int act) {
@@ -86,23 +89,31 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x
 __global__ __launch_bounds__(256) void ss_gather_kernel(const float* __restrict__ T, const float* __restrict__ Ct,
                                                         const float* __restrict__ bias, const int32_t* __restrict__ cursor,
                                                         const int64_t* __restrict__ classes, const unsigned char* __restrict__ keep,
-                                                        int ncls, float* __restrict__ out, int N) {
+                                                        int ncls, float* __restrict__ out, int N, int S) {
   const int b = blockIdx.y;
   const int o4 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (o4 >= N) return;
   const int step = *cursor;
   const bool kept = keep ? keep[b] != 0 : true;
-  const int row = kept ? (int)classes[b] : ncls;
+  const int64_t cls = classes[b];
+  // both indices are device data the launch cannot check (a caller's class id, the replayed loop's cursor): one outside its
+  // table poisons the row with NaN — a visibly broken sample — instead of reading whatever lies beside the table
+  if ((unsigned)step >= (unsigned)S || (kept && (cls < 0 || cls >= ncls))) {
+    const float q = __builtin_nanf("");
+    st4(out + (size_t)b * N + o4, make_float4(q, q, q, q));
+    return;
+  }
+  const int row = kept ? (int)cls : ncls;
   const float4 t = ld4(T + (size_t)step * N + o4), c = ld4(Ct + (size_t)row * N + o4), bb = ld4(bias + o4);
   st4(out + (size_t)b * N + o4, make_float4((t.x + c.x) + bb.x, (t.y + c.y) + bb.y, (t.z + c.z) + bb.z, (t.w + c.w) + bb.w));
 }
 
 extern "C" int dmh_ss_gather(const float* T, const float* C, const float* bias, const int32_t* cursor, const int64_t* classes,
-                             const uint8_t* keep, int ncls, float* out, int B, int N, void* stream) {
-  DMH_REQUIRE(T && C && bias && cursor && classes && out && B > 0 && N > 0 && N % 4 == 0 && ncls > 0 && B <= 65535,
+                             const uint8_t* keep, int ncls, float* out, int B, int N, int S, void* stream) {
+  DMH_REQUIRE(T && C && bias && cursor && classes && out && B > 0 && N > 0 && N % 4 == 0 && ncls > 0 && B <= 65535 && S > 0,
               "dmh_ss_gather: bad arguments");
   hipLaunchKernelGGL(ss_gather_kernel, dim3(cdiv(N / 4, 256), B), dim3(256), 0, (hipStream_t)stream, T, C, bias, cursor, classes,
-                     keep, ncls, out, N);
+                     keep, ncls, out, N, S);
   DMH_CHECK_LAUNCH("dmh_ss_gather");
   return DMH_OK;
 }
@@ -117,10 +128,10 @@ extern "C" int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* 
 }
 
 extern "C" int dmh_class_embed(const int64_t* classes, const uint8_t* keep, const float* table, const float* null_emb,
-                               float* out, int R, int dim, void* stream) {
-  DMH_REQUIRE(classes && table && null_emb && out && R > 0 && dim > 0, "dmh_class_embed: bad arguments");
+                               float* out, int R, int dim, int num_classes, void* stream) {
+  DMH_REQUIRE(classes && table && null_emb && out && R > 0 && dim > 0 && num_classes > 0, "dmh_class_embed: bad arguments");
   hipLaunchKernelGGL(class_embed_kernel, dim3(cdiv(R * dim, 256)), dim3(256), 0, (hipStream_t)stream, classes, keep,
-                     table, null_emb, out, R, dim);
+                     table, null_emb, out, R, dim, num_classes);
   DMH_CHECK_LAUNCH("dmh_class_embed");
   return DMH_OK;
 }

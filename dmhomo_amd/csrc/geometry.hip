@@ -349,19 +349,51 @@ __global__ void dlt_solve4_kernel(const double* __restrict__ src, const double* 
       A[2 * p + 1][j] = rv[j];
     }
   }
-  for (int c = 0; c < 8; ++c) {
-    int piv = c;
-    for (int r = c + 1; r < 8; ++r)
-      if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+  // (rank-deficient systems — repeated or collinear corners — have no pivot to divide by, while the reference's
+  //  torch.linalg.pinv, DDP:1639, returns the finite minimum-norm least-squares solution: such a system is re-solved through
+  //  its Tikhonov-regularised normal equations (A^T A + lambda I) h = A^T b, lambda = 1e-12 * trace / 8, whose solution tends
+  //  to pinv(A) b as lambda -> 0.  Well-posed systems never take this path.)
+  double amax = 0.0;
+  for (int r = 0; r < 8; ++r)
+    for (int j = 0; j < 8; ++j) amax = fmax(amax, fabs(A[r][j]));
+  double M[8][9];
+  for (int i = 0; i < 8; ++i)
     for (int j = 0; j < 9; ++j) {
-      const double t = A[c][j];
-      A[c][j] = A[piv][j];
-      A[piv][j] = t;
+      double t = 0.0;
+      for (int r = 0; r < 8; ++r) t += A[r][i] * A[r][j];
+      M[i][j] = t;
     }
-    const double d = A[c][c];
-    for (int r = c + 1; r < 8; ++r) {
-      const double f = A[r][c] / d;
-      for (int j = c; j < 9; ++j) A[r][j] -= f * A[c][j];
+  bool singular = false;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      if (!singular) break;
+      double tr = 0.0;
+      for (int i = 0; i < 8; ++i) tr += M[i][i];
+      const double lam = (tr > 0.0 ? tr : 1.0) * 1.25e-13;
+      for (int i = 0; i < 8; ++i) {
+        for (int j = 0; j < 9; ++j) A[i][j] = M[i][j];
+        A[i][i] += lam;
+      }
+      amax = 0.0;   // (the regularised system is positive definite: solve it whatever its pivots are)
+    }
+    for (int c = 0; c < 8; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < 8; ++r)
+        if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+      for (int j = 0; j < 9; ++j) {
+        const double t = A[c][j];
+        A[c][j] = A[piv][j];
+        A[piv][j] = t;
+      }
+      const double d = A[c][c];
+      if (!(fabs(d) > 1e-13 * amax)) {
+        singular = true;
+        if (pass == 0) break;
+      }
+      for (int r = c + 1; r < 8; ++r) {
+        const double f = A[r][c] / d;
+        for (int j = c; j < 9; ++j) A[r][j] -= f * A[c][j];
+      }
     }
   }
   double h[8];

@@ -128,6 +128,9 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
   }
 }
 
+// torch.clamp(x, -1., 1.) (CFG:612,634): NaN stays NaN (fminf / fmaxf alone would turn it into -1 and hide a broken row)
+__device__ __forceinline__ float clamp_pm1(float x) { return x != x ? x : fminf(fmaxf(x, -1.f), 1.f); }
+
 __global__ __launch_bounds__(256) void sampler_step_kernel(DmhStep s, const float* __restrict__ mc,
                                                            const float* __restrict__ mn, const float* __restrict__ x,
                                                            const float* __restrict__ noise, float* __restrict__ img_out,
@@ -149,14 +152,14 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(DmhStep s, const floa
     if (s.objective == 0) {  // pred_noise, CFG:614-617
       pn = mo;
       x0 = s.sqrt_recip_ac * xt - s.sqrt_recipm1_ac * pn;
-      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      if (s.clip) x0 = clamp_pm1(x0);
     } else if (s.objective == 1) {  // pred_x0, CFG:619-622
       x0 = mo;
-      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      if (s.clip) x0 = clamp_pm1(x0);
       pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
     } else {  // pred_v, CFG:624-628
       x0 = s.sqrt_ac * xt - s.sqrt_1m_ac * mo;
-      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      if (s.clip) x0 = clamp_pm1(x0);
       pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
     }
     float o;
@@ -196,14 +199,14 @@ __global__ __launch_bounds__(256) void sampler_step_dev_kernel(const DmhStep* __
     if (s.objective == 0) {
       pn = mo;
       x0 = s.sqrt_recip_ac * xt - s.sqrt_recipm1_ac * pn;
-      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      if (s.clip) x0 = clamp_pm1(x0);
     } else if (s.objective == 1) {
       x0 = mo;
-      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      if (s.clip) x0 = clamp_pm1(x0);
       pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
     } else {
       x0 = s.sqrt_ac * xt - s.sqrt_1m_ac * mo;
-      if (s.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+      if (s.clip) x0 = clamp_pm1(x0);
       pn = (s.sqrt_recip_ac * xt - x0) / s.sqrt_recipm1_ac;
     }
     float o;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256) void rows_lincomb_kernel(const float* __restri
     float v = ca[b] * x[i];
     if (y) v = v + cb[b] * y[i];
     if (dv) v = v / dv[b];
-    if (clamp) v = fminf(fmaxf(v, -1.f), 1.f);
+    if (clamp) v = clamp_pm1(v);
     out[i] = v;
   }
 }

@@ -341,7 +341,10 @@ def DLT_solve(src_p, off_set):
     dev = _dev()
     src64 = src_ps.reshape(bs * n, h, w).to(device=dev, dtype=torch.float64)
     off64 = off_sets.reshape(bs * n, h, w).to(device=dev, dtype=torch.float64)
-    return ops.dlt_points(src64, off64).reshape(bs, n, 3, 3)
+    # solved in float64 on the GPU; handed back as the reference's result would be: on the inputs' device, in the dtype its
+    # torch.cat((h8, ones)) promotes to (DDP:1641 — float64 for homo_gen's float64 grid, float32 for float32 points)
+    out_dtype = torch.promote_types(torch.promote_types(src_p.dtype, off_set.dtype), torch.float32)
+    return ops.dlt_points(src64, off64).reshape(bs, n, 3, 3).to(device=src_p.device, dtype=out_dtype)
 
 
 def flow_warp(x, flow12, pad='border', mode='bilinear'):
@@ -491,8 +494,13 @@ class SyntheticConditions:
     [img1(3) img2(3) mask(1) rgb_flow(3) flow(2)] built on device: seeded random
     640x360 homographies -> G1 -> K7 flow / HSV image; mask = union of 3 random rectangles; class 0."""
 
-    def __init__(self, image_size, batch_size, seed=1000, device=None):
-        self.image_size, self.batch_size, self.seed, self.count = image_size, batch_size, seed, 0
+    def __init__(self, image_size, batch_size, seed=1000, device=None, first=0, stride=None):
+        """sample i of the stream is built from ``seed + i``; this iterator yields samples first .. first + batch_size - 1,
+        then advances by ``stride`` (default batch_size): rank r of N with first = r * bs, stride = N * bs walks the samples
+        [b * bs * N + r * bs, + bs) of batch b — the ids ``distributed.noise_key`` gives the rank's noise, so a job's records
+        do not depend on N."""
+        self.image_size, self.batch_size, self.seed, self.count = image_size, batch_size, seed, int(first)
+        self.stride = int(stride) if stride is not None else batch_size
         self.device = device
 
     def _homography(self, g):
@@ -515,7 +523,7 @@ class SyntheticConditions:
                 y0, x0 = int(r[0] * S * 0.6), int(r[1] * S * 0.6)
                 h, w = int((0.25 + 0.3 * r[2]) * S), int((0.25 + 0.3 * r[3]) * S)
                 masks[i, 0, y0:y0 + h, x0:x0 + w] = 1.
-        self.count += B
+        self.count += self.stride
         flow, rgb = homo_to_flow_rgb(np.stack(homos), S, S)
         data = torch.cat([torch.zeros((B, 6, S, S), device=dev), masks.to(dev), rgb, flow], dim=1)
         return data, torch.zeros((B,), dtype=torch.long, device=dev)
@@ -556,7 +564,10 @@ class Trainer(object):
                                       convert_image_to=convert_image_to, workers=max(1, num_worker))
             self.dl = ConditionLoader(self.ds, train_batch_size, shuffle=shuffle, rank=rank, world=world)
         elif isinstance(folder, (str, os.PathLike)):
-            self.dl = SyntheticConditions(self.image_size, train_batch_size, seed=1000 + 100003 * rank)
+            # sample g of the JOB is built from seed 1000 + g whatever the number of ranks (rank r holds rows
+            # [b * bs * world + r * bs, + bs) of batch b: the ids distributed.key_noise_by_sample keys its noise with)
+            self.dl = SyntheticConditions(self.image_size, train_batch_size, seed=1000, first=rank * train_batch_size,
+                                          stride=world * train_batch_size)
         else:
             self.dl = iter(folder)
         self.ema = EMA(diffusion_model, beta=ema_decay, update_every=ema_update_every)

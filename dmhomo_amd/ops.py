@@ -333,7 +333,7 @@ def class_embed(classes, keep, table, null_emb):
     R, dim = classes.shape[0], table.shape[1]
     out = _empty((R, dim), table)
     call('dmh_class_embed', ptr(classes, torch.int64), ptr(keep, torch.uint8), ptr(table), ptr(null_emb), ptr(out), R,
-         dim)
+         dim, table.shape[0])
     return out
 
 
@@ -358,7 +358,7 @@ def ss_gather(T, Ct, bias, cursor, classes, keep, out=None):
         out = _empty((B, N), T)
     assert out.shape == (B, N) and out.is_contiguous() and Ct.shape[1] == N and bias.shape == (N,)
     call('dmh_ss_gather', ptr(T), ptr(Ct), ptr(bias), ptr(cursor, torch.int32), ptr(classes, torch.int64),
-         ptr(keep, torch.uint8), Ct.shape[0] - 1, ptr(out), B, N)
+         ptr(keep, torch.uint8), Ct.shape[0] - 1, ptr(out), B, N, T.shape[0])
     return out
 
 

@@ -237,9 +237,10 @@ int dmh_attention(const float* qkv, float* out, int B, int n, float scale, const
  * ------------------------------------------------------------------------------------- */
 /* N7  SinusoidalPosEmb, CFG:165-172: out[r] = (sin(t_r*f), cos(t_r*f)); freq[dim/2] fp32 table */
 int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* out, int R, int dim, void* stream);
-/* N8  classes_emb lookup + null swap, CFG:419-425: keep==NULL keeps every row */
+/* N8  classes_emb lookup + null swap, CFG:419-425: keep==NULL keeps every row; table [num_classes][dim] — a kept class id
+ * outside [0, num_classes) yields a NaN row (device data: it cannot be refused at launch) */
 int dmh_class_embed(const int64_t* classes, const uint8_t* keep, const float* table, const float* null_emb,
-                    float* out, int R, int dim, void* stream);
+                    float* out, int R, int dim, int num_classes, void* stream);
 /* y[r][o] = act_out( sum_i act_in(x[r][i]) * wt[i][o] + bias[o] ), wt = W^T [in][out].
  * act: 0 none, 1 SiLU, 2 GELU(erf).  (time_mlp / classes_mlp CFG:353,362; ResnetBlock.mlp CFG:220) */
 int dmh_linear(const float* x, int64_t x_stride, const float* wt, const float* bias, float* y, int64_t y_stride,
@@ -249,9 +250,10 @@ int dmh_linear(const float* x, int64_t x_stride, const float* wt, const float* b
  * of a REPLAYED denoise step from tables: out[b][0..N) = (T[*cursor] + C[keep[b] ? classes[b] : ncls]) + bias, with T [S][N] the
  * time half's partial sums of dmh_linear per denoise step and C [ncls+1][N] the class half's per class (last row: null
  * embedding), both made by dmh_linear itself on inputs whose other half is zero; bitwise dmh_linear on the full input.
- * cursor: the step cursor of dmh_sampler_seek (device); keep may be NULL (every class kept). */
+ * cursor: the step cursor of dmh_sampler_seek (device); keep may be NULL (every class kept).  S = rows of T: a cursor outside
+ * [0, S) or a kept class outside [0, ncls) cannot be refused at launch (device data) and yields a NaN row. */
 int dmh_ss_gather(const float* T, const float* C, const float* bias, const int32_t* cursor, const int64_t* classes,
-                  const uint8_t* keep, int ncls, float* out, int B, int N, void* stream);
+                  const uint8_t* keep, int ncls, float* out, int B, int N, int S, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * K6  sampler glue (NCHW at the API boundary)

@@ -12,8 +12,13 @@ Differences from the reference script (DGM/dgm_sample.py:11-101), all forced by 
   * multi-GPU: launch with torch.distributed.run instead of N hand-started processes (--gpu_nums / -i are
     still accepted and select the data slice exactly as the reference's unused arguments did: not at all); rank 0
     alone reads the checkpoint and broadcasts the online + EMA weights over RCCL (the reference's N processes each
-    load the file, SAMPLE:54); sampling replays one captured denoise step from a HIP graph; noise is keyed by --seed and
-    the global sample index (dmh_rng_indexed), so N processes produce the records one process would.
+    load the file, SAMPLE:54); sampling replays one captured denoise step from a HIP graph, with the conditional pass's
+    dropped rows not computed (cfg.Unet.dedup_dropped_rows: the same samples bit for bit); noise is keyed by --seed and
+    the global sample index (dmh_rng_indexed).  With the synthetic conditions sample g of the job is also BUILT from
+    g (ddpm.SyntheticConditions), so N processes write, between them, exactly the records one process writes in N times
+    as many batches (tests/test_gpu_distributed.py).  With a dataset folder the loader deals rows to ranks in strides
+    (dataset.ConditionLoader, as accelerate's sharded DataLoader does) while noise ids are contiguous per rank: the
+    records are reproducible for a given N, but which noise meets which image depends on N.
 Output: traindata/<exp>/dataset/idx_<i>_rank_<r>_part_<p>_dm_cahomo_<k>k.npy — a pickled list of
 {"imgs": uint8 (B,6,H,W), "homos": float64 (B,3,3)} every 2 batches (SAMPLE:73-77), the format
 HEM/dataset/data_loader.py:123-131 consumes.
@@ -68,6 +73,7 @@ def main():
     sampler = trainer.ema.ema_model                        # what Trainer.sample draws from (DDP:1960)
     sampler.model.cfg_mode = 'streams'
     sampler.hip_graph = True                               # one captured denoise step replayed s_step times
+    sampler.model.dedup_dropped_rows = True                # CFG:404,415-425: dropped conditional rows == null rows, not computed
     out_dir = f'traindata/{args.exp}/dataset/'
     os.makedirs(out_dir, exist_ok=True)
     train_list, part = [], args.part
@@ -75,6 +81,8 @@ def main():
         # noise keyed by (seed, GLOBAL sample index): rank r of N draws rows [b*bs*N + r*bs, +bs) of the job's noise, so
         # the noise of a sample does not depend on how many processes made the job (the reference's N hand-started
         # processes, SAMPLE:13-18, each draw from their own default generator: torch seeds it at random per process)
+        # (a loader that ends on a short batch — dataset.ConditionLoader keeps it, like the reference's DataLoader — draws
+        #  the first rows' ids: cfg.DeviceRng.ids_for)
         D.key_noise_by_sample(sampler, args.seed, args.bs * world, first_id=b * args.bs * world, device=device)
         ret = trainer.sample(args.i, device, step=len(train_list))
         train_list.append(ret)

@@ -83,6 +83,58 @@ def test_world2_gloo():
     assert torch.equal(torch.tensor(u0 + u1), torch.from_numpy(ORNG.uniform(seed, ids, 6)[:, 0]))
 
 
+def _worker8(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from dmhomo_amd import distributed as D
+    from dmhomo_amd import cfg
+    r, w, device = D.init_from_env('gloo')
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)
+    m = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1)
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=50, sampling_timesteps=4, objective='pred_x0')
+    if rank == world - 1:
+        d.betas.add_(1.0)
+    D.broadcast_module_(d, src=0)          # the payload is cut into `world` pieces: scatter + all_gather at world 8
+    digest = float(sum(p.double().sum() for p in d.state_dict().values()))
+    total = 25                             # BASELINE configs[1]'s batch dealt to configs[2]'s 8 ranks: shards 4, 3, 3, ...
+    lo, hi = D.shard_bounds(total, rank, world)
+    imgs = torch.arange(lo, hi, dtype=torch.uint8).reshape(-1, 1, 1, 1).expand(-1, 6, 2, 2).contiguous()
+    homos = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1, 1).expand(-1, 3, 3).contiguous()
+    gi, gh = D.gather_records(imgs, homos, dst=0)
+    seed, ids = D.noise_key(7, total, rank, world, first_id=500)
+    q.put((rank, digest, (lo, hi), None if gi is None else gi[:, 0, 0, 0].tolist(),
+           None if gh is None else gh[:, 0, 0].tolist(), seed, list(ids)))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_world8_gloo():
+    """world_size 8 — the process count of BASELINE configs[2] / configs[3] — on the host: weight payload in 8 pieces, uneven
+    contiguous shards of a 25-sample job, the size-exchanged gather in rank order, the ranks' noise keys concatenating to the
+    one-process key"""
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert len({t[1] for t in res}) == 1                 # identical weights + buffers on all 8 ranks
+    spans = [t[2] for t in res]
+    assert spans == [(0, 4), (4, 7), (7, 10), (10, 13), (13, 16), (16, 19), (19, 22), (22, 25)]
+    assert res[0][3] == list(range(25)) and res[0][4] == [float(i) for i in range(25)]
+    assert all(t[3] is None and t[4] is None for t in res[1:])
+    from dmhomo_amd import distributed as D
+    assert all(t[5] == 7 for t in res)
+    assert sum((t[6] for t in res), []) == list(D.noise_key(7, 25, 0, 1, first_id=500)[1])
+
+
 def _ckpt_worker(rank, world, port, q, folder):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
@@ -160,6 +212,13 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['rccl_ranks'] == 2 and res['records_in_rank_order'] and res['global_batch'] == 6
+    # ... and the 8 ranks of BASELINE configs[2]
+    env8 = dict(env, OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--device', 'cpu', '--bs', '3',
+                        '--steps', '2', '--warmup', '0'], capture_output=True, text=True, env=env8, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert res['n_gpus'] == 8 and res['rccl_ranks'] == 8 and res['records_in_rank_order'] and res['global_batch'] == 24
     # outside the test the CPU mode refuses to run, and a failing child makes the launcher exit non-zero
     env.pop('DMH_BENCH_PLUMBING_TEST')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--device', 'cpu'],

@@ -178,3 +178,26 @@ def test_sample_bs25_s32_dedup_graph_bitwise():
     assert torch.isfinite(ref).all() and float(ref.min()) >= 0 and float(ref.max()) <= 1
     assert torch.equal(outs['streams', True], ref)
     assert torch.equal(outs['batched', True], ref)
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_invalid_class_id_poisons_its_row_only(graph):
+    """a class id outside the embedding table (the reference's nn.Embedding raises, CFG:419) is device data here: the row comes
+    out NaN — in the eager path (dmh_class_embed) and in the replayed step (dmh_ss_gather) — and the other rows are untouched"""
+    from dmhomo_amd import cfg
+    m, _ = make_cfg(8, cond_drop_prob=0.)            # every class kept: the bad id is always looked up
+    m.cfg_mode = 'streams'
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=3, objective='pred_x0').to(dev())
+    d.hip_graph = graph
+    _, rf, mk = _cond_inputs(3, 16, 910)
+    rf01, flow, mk = g((rf + 1) / 2), g(rand((3, 2, 16, 16), 911)), g(mk)
+    outs = []
+    for classes in ([0, 0, 0], [0, 5, 0], [0, -1, 0]):
+        d.rng.key_by_sample(3, range(3), dev())
+        outs.append(d.sample(g(torch.tensor(classes)), rf01, flow, mk)[0].clone())
+    d.hip_graph = False
+    d.rng.unkey()
+    assert torch.isfinite(outs[0]).all()
+    for bad in outs[1:]:
+        assert torch.isnan(bad[1]).all()
+        assert torch.equal(bad[[0, 2]], outs[0][[0, 2]])

@@ -69,11 +69,12 @@ sys.path.insert(0, os.environ['DMH_ROOT'])
 from dmhomo_amd import cfg, ddpm, ops
 from dmhomo_amd import distributed as D
 rank, world, device = D.init_from_env()              # DMH_DIST_BACKEND=gloo, DMH_SHARE_GPU=1: both ranks on cuda:0
-assert world == 2 and device.type == 'cuda' and dist.get_backend() == 'gloo'
-S, total, steps = 128, 6, 4
+assert world == int(os.environ['DMH_WANT_WORLD']) and device.type == 'cuda' and dist.get_backend() == 'gloo'
+dim, S, total, steps = (64, 128, 6, 4) if world == 2 else (8, 16, 25, 4)     # 25 samples over 8 ranks: shards of 4 and 3
 torch.manual_seed(100 + rank)                        # different weights per rank: rank 0's must win
-model = cfg.Unet(dim=64, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
+model = cfg.Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1)
 model.cfg_mode = 'streams'
+model.dedup_dropped_rows = world > 2                 # (the 8-rank job also skips the conditional pass's dropped rows)
 d = cfg.GaussianDiffusion(model, image_size=S, timesteps=1000, sampling_timesteps=steps, objective='pred_x0').to(device)
 D.broadcast_module_(d, src=0)
 d.hip_graph = True
@@ -92,14 +93,17 @@ u8, hm = run(lo, hi, ids)
 gi, gh = D.gather_records(u8, hm, dst=0)
 t = torch.tensor([float(rank + 1)], device=device, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-assert t.item() == 2.0
+assert t.item() == float(world)
+sizes = [None] * world
+dist.all_gather_object(sizes, hi - lo)
+assert sum(sizes) == total and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
 if rank == 0:
     assert gi.shape == (total, 6, S, S) and gh.shape == (total, 3, 3)
     wi, wh = run(0, total, range(total))             # the same job in ONE process
     assert torch.equal(gi, wi), int((gi != wi).sum())
     assert torch.equal(gh, wh)
     assert not torch.equal(gi[0], gi[3])
-    print('TWO-RANKS-OK')
+    print('RANKS-OK', sizes)
 else:
     assert gi is None and gh is None
 dist.barrier()
@@ -107,12 +111,16 @@ dist.destroy_process_group()
 '''
 
 
-def test_two_ranks_shard_a_job_and_reproduce_the_single_process_records(tmp_path):
+@pytest.mark.parametrize('ranks', [2, 8])
+def test_ranks_shard_a_job_and_reproduce_the_single_process_records(tmp_path, ranks):
     """BASELINE configs[2]'s data path with more than one rank on real hardware, as far as a one-GPU box allows: two
     processes (torch.distributed.run) time-share the GPU and talk over gloo (RCCL refuses two ranks on one device) — weights
     of rank 0 reach rank 1 (scatter + all-gather payload), each rank samples its shard of a 6-sample job at the real geometry
     (dim 64, 128x128, 'streams', per-step HIP graph, noise keyed by global sample index), the uint8 records and homographies
-    are gathered in rank order — and rank 0 checks them BITWISE against the same job run in one process."""
+    are gathered in rank order — and rank 0 checks them BITWISE against the same job run in one process.
+    ranks = 8 (BASELINE configs[2]'s process count; a small model so that 8 contexts fit beside each other): a 25-sample job,
+    i.e. UNEVEN shards (4, 3, 3, ...): shard bounds, the size-exchanged gather and the payload at the world size the driver's
+    8-GPU run uses, with the conditional pass's dropped rows skipped."""
     import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as sk:
@@ -121,65 +129,82 @@ def test_two_ranks_shard_a_job_and_reproduce_the_single_process_records(tmp_path
     script = tmp_path / 'two_ranks.py'
     script.write_text(TWO_RANKS)
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    env.update(DMH_ROOT=root, DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr',
+    env.update(DMH_ROOT=root, DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2',
+               DMH_WANT_WORLD=str(ranks))
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ranks}', '--master-addr',
                         '127.0.0.1', '--master-port', str(port), str(script)], capture_output=True, text=True, env=env, cwd=root,
                        timeout=900)
     print(r.stdout[-2000:], r.stderr[-3000:])
-    assert r.returncode == 0 and 'TWO-RANKS-OK' in r.stdout
+    assert r.returncode == 0 and 'RANKS-OK' in r.stdout
 
 
-@pytest.mark.parametrize('ranks', [1, 2])
+@pytest.mark.parametrize('ranks', [1, 2, 8])
 def test_dgm_sample_script_end_to_end(tmp_path, ranks):
     """scripts/dgm_sample.py (the counterpart of DGM/dgm_sample.py: same flags, same record files) as a user starts it —
-    one process, and two processes under torch.distributed.run (time-sharing the GPU over gloo on this one-GPU box): rank 0
+    one process, and 2 / 8 processes under torch.distributed.run (time-sharing the GPU over gloo on this one-GPU box): rank 0
     alone would read the checkpoint (none here: the seeded initialisation is broadcast), every rank writes its part file in the
-    reference's list-of-dict format, the records are uint8 (bs, 6, S, S) + float64 (bs, 3, 3), and — noise being keyed by the
-    global sample index — the two ranks' records differ from each other while a repeated run reproduces them bit for bit."""
+    reference's list-of-dict format, the records are uint8 (bs, 6, S, S) + float64 (bs, 3, 3), a repeated run reproduces them
+    bit for bit, and — noise AND synthetic conditions being keyed by the global sample index — the N ranks' records are, between
+    them, bit for bit the records ONE process writes in N times as many batches (rank r's batch b = the single process's
+    batch b * N + r)."""
     import socket
     import numpy as np
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(root, 'scripts', 'dgm_sample.py')
-    args = ['-c', 'absent', '--s_step', '3', '--bs', '3', '--exp', 'run0', '--image_size', '128', '--batches', '2', '--seed', '5']
+    S, bs = (128, 3) if ranks <= 2 else (32, 1)
+    base = ['-c', 'absent', '--s_step', '3', '--bs', str(bs), '--exp', 'run0', '--image_size', str(S), '--seed', '5']
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4', PYTHONPATH=root)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2', PYTHONPATH=root)
+    tag = f'{2 * bs / 1000}k'
 
-    def run(workdir):
+    def run(workdir, n, batches):
         os.makedirs(workdir)
-        if ranks == 1:
+        args = base + ['--batches', str(batches)]
+        if n == 1:
             cmd = [sys.executable, script] + args
             e = env
         else:
             with socket.socket() as sk:
                 sk.bind(('127.0.0.1', 0))
                 port = sk.getsockname()[1]
-            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ranks}', '--master-addr',
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr',
                    '127.0.0.1', '--master-port', str(port), script] + args
             e = dict(env, DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1')
-        r = subprocess.run(cmd, capture_output=True, text=True, env=e, cwd=workdir, timeout=900)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=e, cwd=workdir, timeout=1200)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         out = {}
-        for rk in range(ranks):
-            f = os.path.join(workdir, 'traindata', 'run0', 'dataset', f'idx_0_rank_{rk}_part_0_dm_cahomo_0.006k.npy')
-            assert os.path.exists(f), os.listdir(os.path.join(workdir, 'traindata', 'run0', 'dataset'))
-            recs = np.load(f, allow_pickle=True)
-            assert len(recs) == 2
+        for rk in range(n):
+            recs = []
+            for part in range(batches // 2):
+                f = os.path.join(workdir, 'traindata', 'run0', 'dataset', f'idx_0_rank_{rk}_part_{part}_dm_cahomo_{tag}.npy')
+                assert os.path.exists(f), os.listdir(os.path.join(workdir, 'traindata', 'run0', 'dataset'))
+                got = np.load(f, allow_pickle=True)
+                assert len(got) == 2
+                recs.extend(got)
             for rec in recs:
-                assert rec['imgs'].dtype == np.uint8 and rec['imgs'].shape == (3, 6, 128, 128)
-                assert rec['homos'].dtype == np.float64 and rec['homos'].shape == (3, 3, 3)
+                assert rec['imgs'].dtype == np.uint8 and rec['imgs'].shape == (bs, 6, S, S)
+                assert rec['homos'].dtype == np.float64 and rec['homos'].shape == (bs, 3, 3)
             out[rk] = recs
         return out
-    a, b = run(str(tmp_path / 'a')), run(str(tmp_path / 'b'))
-    for rk in range(ranks):
-        for x, y in zip(a[rk], b[rk]):
-            assert np.array_equal(x['imgs'], y['imgs']) and np.array_equal(x['homos'], y['homos'])
+
+    def same(x, y):
+        return np.array_equal(x['imgs'], y['imgs']) and np.array_equal(x['homos'], y['homos'])
+    a = run(str(tmp_path / 'a'), ranks, 2)
     assert not np.array_equal(a[0][0]['imgs'], a[0][1]['imgs'])               # the second batch draws new noise
-    if ranks == 2:
-        assert not np.array_equal(a[0][0]['imgs'], a[1][0]['imgs'])
+    if ranks == 1:
+        b = run(str(tmp_path / 'b'), 1, 2)
+        assert all(same(x, y) for x, y in zip(a[0], b[0]))
+        return
+    assert not np.array_equal(a[0][0]['imgs'], a[1][0]['imgs'])
+    one = run(str(tmp_path / 'one'), 1, 2 * ranks)[0]                         # the same job in ONE process
+    for rk in range(ranks):
+        for b_ in range(2):
+            assert same(a[rk][b_], one[b_ * ranks + rk]), (rk, b_)
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """`python bench.py --gpus 2` end to end on real hardware — the launcher starts two ranks, the weight payload travels, each
+@pytest.mark.parametrize('ranks,extra', [(2, ['--bs', '4']), (8, ['--bs', '3', '--dim', '8', '--image_size', '16'])])
+def test_bench_ranks_on_one_gpu(ranks, extra):
+    """`python bench.py --gpus 2` (and `--gpus 8` on a small model) end to end on real hardware — the launcher starts two ranks, the weight payload travels, each
     rank samples its shard (per-step graph, keyed noise), records are gathered every step, the time is the maximum over
     ranks, rank 0 prints ONE line — with the two ranks time-sharing the box's one GPU over gloo (the driver's 8-GPU run is the
     same code over RCCL)."""
@@ -187,12 +212,13 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--bs', '4', '--s_step', '4', '--steps', '2',
-                        '--warmup', '1', '--no-cpu-baseline', '--no-roofline'], capture_output=True, text=True, env=env, cwd=root,
-                       timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(ranks), '--s_step', '4', '--steps', '2',
+                        '--warmup', '1', '--no-cpu-baseline', '--no-roofline'] + extra, capture_output=True, text=True, env=env,
+                       cwd=root, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['backend'] == 'gloo' and d['scaling'] == 'weak'
-    assert d['config']['global_batch'] == 8 and d['value'] > 0 and d['steps'] == 2
+    assert d['n_gpus'] == ranks and d['rccl_ranks'] == ranks and d['backend'] == 'gloo' and d['scaling'] == 'weak'
+    assert d['config']['global_batch'] == int(extra[1]) * ranks and d['value'] > 0 and d['steps'] == 2
+    assert d['variants']['dedup_dropped_rows']['value'] > 0

@@ -33,10 +33,10 @@ def T(a):
     return torch.from_numpy(np.asarray(a))
 
 
-def make_cfg(dim, seed=0, **kw):
+def make_cfg(dim, seed=0, out_scale=1.0, **kw):
     from dmhomo_amd import cfg
     m = cfg.Unet(dim=dim, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1, **kw)
-    sd = det_state_dict(shapes_of(m), seed)
+    sd = det_state_dict(shapes_of(m), seed, out_scale)
     m.load_state_dict(sd)
     return m.to(dev()), sd
 
