@@ -123,6 +123,7 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p]),
     'dmh_attention': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p, C.c_void_p]),
     'dmh_sinusoidal_embed': (c_int, [C.c_void_p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
+    'dmh_fourier_embed': (c_int, [C.c_void_p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     'dmh_class_embed': (c_int, [C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p]),
     'dmh_linear': (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_int, c_int,
                            C.c_void_p]),
@@ -152,7 +153,7 @@ SIGNATURES = {
     'dmh_to_uint8': (c_int, [c_f32p, C.c_void_p, c_i64, C.c_void_p]),
     'dmh_homography_flow': (c_int, [C.c_void_p, c_f32p, c_f32p, c_int, c_int, c_int, c_float, C.c_void_p]),
     'dmh_flow_to_image': (c_int, [c_f32p, c_f32p, c_int, c_int, c_float, C.c_void_p]),
-    'dmh_flow_warp': (c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, c_int, c_int, c_int, c_int,
+    'dmh_flow_warp': (c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                               C.c_void_p]),
     'dmh_dlt_homography': (c_int, [c_f32p, C.c_void_p, C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
 }

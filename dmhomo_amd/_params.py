@@ -20,6 +20,17 @@ class Holder(nn.Module):
         raise RuntimeError('dmhomo_amd parameter holders are not executable modules')
 
 
+def time_embedding(dim, learned_sinusoidal_cond, random_fourier_features, learned_sinusoidal_dim):
+    """slot 0 of ``time_mlp`` and the width it feeds time_mlp.1 with (CFG:344-353 / DDP:348-364): SinusoidalPosEmb has no
+    parameters; RandomOrLearnedSinusoidalPosEmb holds ``weights`` (half_dim,), frozen when random (CFG:182-183)."""
+    h = Holder()
+    if learned_sinusoidal_cond or random_fourier_features:
+        assert learned_sinusoidal_dim % 2 == 0
+        h.weights = nn.Parameter(torch.randn(learned_sinusoidal_dim // 2), requires_grad=not random_fourier_features)
+        return h, learned_sinusoidal_dim + 1
+    return h, dim
+
+
 def gain(dim):
     h = Holder()
     h.g = nn.Parameter(torch.ones(1, dim, 1, 1))             # LayerNorm.g, CFG:135

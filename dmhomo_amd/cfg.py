@@ -131,10 +131,9 @@ class Unet(nn.Module):
         self.init_conv = nn.Conv2d(input_channels, init_dim, 7, padding=3)
         time_dim = dim * 4
         self.random_or_learned_sinusoidal_cond = learned_sinusoidal_cond or random_fourier_features
-        if self.random_or_learned_sinusoidal_cond:
-            # CFG:514-515: GaussianDiffusion refuses such a model, so it cannot reach the sampling path
-            raise NotImplementedError('learned / random sinusoidal embeddings are outside the DGM sampling path')
-        self.time_mlp = nn.Sequential(P.Holder(), nn.Linear(dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
+        # (GaussianDiffusion refuses such a model — CFG:514-515 — so it serves bare Unet.forward callers only)
+        pos_emb, fourier_dim = P.time_embedding(dim, learned_sinusoidal_cond, random_fourier_features, learned_sinusoidal_dim)
+        self.time_mlp = nn.Sequential(pos_emb, nn.Linear(fourier_dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
         self.classes_emb = nn.Embedding(num_classes, dim)
         self.null_classes_emb = nn.Parameter(torch.randn(dim))
         classes_dim = dim * 4

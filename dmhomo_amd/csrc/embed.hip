@@ -13,6 +13,21 @@ __global__ void sinusoidal_embed_kernel(const int64_t* __restrict__ t, const flo
   out[(size_t)r * dim + half + i] = cosf(arg);
 }
 
+// RandomOrLearnedSinusoidalPosEmb (CFG:185-190): out[r] = (t_r, sin(t_r w_i 2 pi) ..., cos(t_r w_i 2 pi) ...), the products in the
+// reference's order ((t * w) * 2) * pi in fp32
+__global__ void fourier_embed_kernel(const int64_t* __restrict__ t, const float* __restrict__ w, float* __restrict__ out, int R,
+                                     int half) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= R * half) return;
+  const int r = idx / half, i = idx % half;
+  const float x = (float)t[r];
+  const float arg = ((x * w[i]) * 2.0f) * 3.14159265358979323846f;
+  float* o = out + (size_t)r * (2 * half + 1);
+  if (i == 0) o[0] = x;
+  o[1 + i] = sinf(arg);
+  o[1 + half + i] = cosf(arg);
+}
+
 // N8: classes_emb(classes) with rows swapped for null_classes_emb where keep == 0 (CFG:419-425)
 __global__ void class_embed_kernel(const int64_t* __restrict__ classes, const uint8_t* __restrict__ keep,
                                    const float* __restrict__ table, const float* __restrict__ null_emb,
@@ -124,6 +139,14 @@ extern "C" int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* 
   hipLaunchKernelGGL(sinusoidal_embed_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, t, freq, out,
                      R, dim);
   DMH_CHECK_LAUNCH("dmh_sinusoidal_embed");
+  return DMH_OK;
+}
+
+extern "C" int dmh_fourier_embed(const int64_t* t, const float* weights, float* out, int R, int half, void* stream) {
+  DMH_REQUIRE(t && weights && out && R > 0 && half > 0, "dmh_fourier_embed: bad arguments");
+  hipLaunchKernelGGL(fourier_embed_kernel, dim3(cdiv(R * half, 256)), dim3(256), 0, (hipStream_t)stream, t, weights, out, R,
+                     half);
+  DMH_CHECK_LAUNCH("dmh_fourier_embed");
   return DMH_OK;
 }
 

@@ -67,6 +67,59 @@ __global__ __launch_bounds__(256) void homography_flow_kernel(const double* __re
 //   g  = 2.0*v/(W-1) - 1.0;  ix = (g+1)*((W-1)/2);  ix = min(W-1, max(ix, 0));  x0 = floor(ix)
 //   w = ix-x0, e = (x0+1)-ix, n = iy-y0, s = (y0+1)-iy
 //   out = fma(se, n*w, fma(sw, n*e, fma(ne, s*w, nw*(s*e))))
+// pad: 0 'border' (the reference's default: coordinates clipped to the image), 1 'zeros' (taps outside the image read 0),
+// 2 'reflection' (reflected about the border pixels' centres, then clipped) — grid_sample's padding_mode with
+// align_corners=True (ATen/native/GridSampler.h: clip_coordinates, reflect_coordinates).  mode: 0 'bilinear', 1 'nearest'
+// (nearbyint, ties to even).
+__device__ __forceinline__ float gs_reflect(float in, int size) {  // reflect_coordinates(in, 0, 2 * (size - 1))
+  if (size <= 1) return 0.f;
+  const float span = (float)(size - 1);
+  in = fabsf(in);
+  const float extra = fmodf(in, span);
+  const int flips = (int)floorf(in / span);
+  return (flips & 1) == 0 ? extra : span - extra;
+}
+__device__ __forceinline__ float gs_coord(float g, int size, int pad) {
+  float i = (g + 1.f) * ((float)(size - 1) / 2.f);
+  if (pad == 2) i = gs_reflect(i, size);
+  if (pad != 1) i = fminf((float)(size - 1), fmaxf(i, 0.f));
+  return i;
+}
+__global__ __launch_bounds__(256) void flow_warp_general_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                                float* __restrict__ out, int C, int H, int W, int pad, int mode) {
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= H * W) return;
+  const int yi = p / W, xi = p % W;
+  const size_t hw = (size_t)H * W;
+  const float vx = (float)xi + flow[((size_t)b * 2 + 0) * hw + p];
+  const float vy = (float)yi + flow[((size_t)b * 2 + 1) * hw + p];
+  const float gx = 2.0f * vx / (float)(W - 1) - 1.0f;
+  const float gy = 2.0f * vy / (float)(H - 1) - 1.0f;
+  const float ix = gs_coord(gx, W, pad), iy = gs_coord(gy, H, pad);
+  auto tap = [&](const float* xc, float fx, float fy) -> float {   // within_bounds_2d ? value : 0
+    // (a NaN or far-away coordinate compares false / falls outside: 0, as safe_get / the masked gather give)
+    if (!(fx >= 0.f && fx <= (float)(W - 1) && fy >= 0.f && fy <= (float)(H - 1))) return 0.f;
+    return xc[(size_t)(int)fy * W + (int)fx];
+  };
+  if (mode == 1) {
+    const float nx = nearbyintf(ix), ny = nearbyintf(iy);
+    for (int c = 0; c < C; ++c) out[((size_t)b * C + c) * hw + p] = tap(x + ((size_t)b * C + c) * hw, nx, ny);
+    return;
+  }
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const float w = ix - fx0, e = (fx0 + 1.f) - ix, n = iy - fy0, s = (fy0 + 1.f) - iy;
+  const float wnw = s * e, wne = s * w, wsw = n * e, wse = n * w;
+  for (int c = 0; c < C; ++c) {
+    const float* xc = x + ((size_t)b * C + c) * hw;
+    float acc = tap(xc, fx0, fy0) * wnw;
+    acc = fmaf(tap(xc, fx0 + 1.f, fy0), wne, acc);
+    acc = fmaf(tap(xc, fx0, fy0 + 1.f), wsw, acc);
+    acc = fmaf(tap(xc, fx0 + 1.f, fy0 + 1.f), wse, acc);
+    out[((size_t)b * C + c) * hw + p] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict__ x, const float* __restrict__ flow,
                                                         float* __restrict__ out, int32_t* __restrict__ x0o,
                                                         int32_t* __restrict__ y0o, int C, int H, int W) {
@@ -232,8 +285,16 @@ extern "C" int dmh_flow_to_image(const float* flow, float* rgb, int B, int HW, f
 }
 
 extern "C" int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, int32_t* y0, int B, int C,
-                             int H, int W, void* stream) {
+                             int H, int W, int pad, int mode, void* stream) {
   DMH_REQUIRE(x && flow && out && B > 0 && C > 0 && H > 1 && W > 1, "dmh_flow_warp: bad arguments");
+  DMH_REQUIRE(pad >= 0 && pad <= 2 && mode >= 0 && mode <= 1, "dmh_flow_warp: pad=%d (0 border, 1 zeros, 2 reflection), mode=%d (0 bilinear, 1 nearest)", pad, mode);
+  if (pad != 0 || mode != 0) {
+    DMH_REQUIRE(!x0 && !y0, "dmh_flow_warp: the corner indices are an output of the default (border, bilinear) form only");
+    hipLaunchKernelGGL(flow_warp_general_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, x, flow, out, C,
+                       H, W, pad, mode);
+    DMH_CHECK_LAUNCH("dmh_flow_warp");
+    return DMH_OK;
+  }
   hipLaunchKernelGGL(flow_warp_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, x, flow, out, x0,
                      y0, C, H, W);
   DMH_CHECK_LAUNCH("dmh_flow_warp");
@@ -351,8 +412,10 @@ __global__ void dlt_solve4_kernel(const double* __restrict__ src, const double* 
   }
   // (rank-deficient systems — repeated or collinear corners — have no pivot to divide by, while the reference's
   //  torch.linalg.pinv, DDP:1639, returns the finite minimum-norm least-squares solution: such a system is re-solved through
-  //  its Tikhonov-regularised normal equations (A^T A + lambda I) h = A^T b, lambda = 1e-12 * trace / 8, whose solution tends
-  //  to pinv(A) b as lambda -> 0.  Well-posed systems never take this path.)
+  //  its Tikhonov-regularised normal equations (A^T A + lambda I) h = A^T b, whose solution tends to pinv(A) b as lambda -> 0;
+  //  lambda = 1e-8 * trace / 8 ~ sqrt(f64 epsilon) * |A|^2 balances the bias (lambda / sigma^2 of the retained directions)
+  //  against the rounding of A^T A (epsilon * |A|^2 / lambda): ~1e-6 of the minimum-norm solution.  Well-posed systems never
+  //  take this path.)
   double amax = 0.0;
   for (int r = 0; r < 8; ++r)
     for (int j = 0; j < 8; ++j) amax = fmax(amax, fabs(A[r][j]));
@@ -369,7 +432,7 @@ __global__ void dlt_solve4_kernel(const double* __restrict__ src, const double* 
       if (!singular) break;
       double tr = 0.0;
       for (int i = 0; i < 8; ++i) tr += M[i][i];
-      const double lam = (tr > 0.0 ? tr : 1.0) * 1.25e-13;
+      const double lam = (tr > 0.0 ? tr : 1.0) * 1.25e-9;
       for (int i = 0; i < 8; ++i) {
         for (int j = 0; j < 9; ++j) A[i][j] = M[i][j];
         A[i][i] += lam;

@@ -37,9 +37,9 @@ class Unet(nn.Module):
         self.init_conv = nn.Conv2d(input_channels, init_dim, 7, padding=3)
         time_dim = dim * 4
         self.random_or_learned_sinusoidal_cond = learned_sinusoidal_cond or random_fourier_features
-        if self.random_or_learned_sinusoidal_cond:
-            raise NotImplementedError('learned / random sinusoidal embeddings are outside the DGM sampling path')
-        self.time_mlp = nn.Sequential(P.Holder(), nn.Linear(dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
+        # (GaussianDiffusion refuses such a model — CFG:514-515 — so it serves bare Unet.forward callers only)
+        pos_emb, fourier_dim = P.time_embedding(dim, learned_sinusoidal_cond, random_fourier_features, learned_sinusoidal_dim)
+        self.time_mlp = nn.Sequential(pos_emb, nn.Linear(fourier_dim, time_dim), nn.GELU(), nn.Linear(time_dim, time_dim))
         self.out_dim = default(out_dim, channels * (1 if not learned_variance else 2))
         P.build_trunk(self, dim, init_dim, dim_mults, input_channels, time_dim, resnet_block_groups, self.out_dim,
                       P.downsample_ddp)
@@ -348,10 +348,12 @@ def DLT_solve(src_p, off_set):
 
 
 def flow_warp(x, flow12, pad='border', mode='bilinear'):
-    """G4, DDP:1262-1280."""
-    if pad != 'border' or mode != 'bilinear':
-        raise NotImplementedError('only the reference\'s defaults (bilinear, border) are built')
-    return ops.flow_warp(x.to(torch.float32).contiguous(), flow12.to(torch.float32).contiguous())
+    """G4, DDP:1262-1280: ``pad`` / ``mode`` are grid_sample's padding_mode / mode (DDP:1270-1274): 'border' | 'zeros' |
+    'reflection' and 'bilinear' | 'nearest' ('bicubic' is not built: no caller in DGM passes anything but the defaults)."""
+    if pad not in ops.FLOW_WARP_PAD or mode not in ops.FLOW_WARP_MODE:
+        raise NotImplementedError(f"flow_warp(pad={pad!r}, mode={mode!r}): built are pad in {sorted(ops.FLOW_WARP_PAD)} and mode "
+                                  f"in {sorted(ops.FLOW_WARP_MODE)} (DDP:1262-1280 forwards both to F.grid_sample)")
+    return ops.flow_warp(x.to(torch.float32).contiguous(), flow12.to(torch.float32).contiguous(), pad=pad, mode=mode)
 
 
 def homo_gen(flow):

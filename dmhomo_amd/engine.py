@@ -78,10 +78,13 @@ class UnetEngine:
         emb_dim = sd['time_mlp.3.weight'].shape[0] * (2 if self.has_classes else 1)
         self.emb_dim = emb_dim
 
-        # N7 frequency table, computed as the reference does it on the host (CFG:167-169)
-        half = self.dim // 2
-        f = math.log(10000) / (half - 1)
-        self.freq = torch.exp(torch.arange(half) * -f).to(dev)
+        # N7 frequency table, computed as the reference does it on the host (CFG:167-169) — or the (learned / random) weights
+        # of RandomOrLearnedSinusoidalPosEmb (CFG:175-190), whose embedding is (t, sin, cos): time_mlp.1 then takes dim + 1
+        self.fourier_w = f32('time_mlp.0.weights') if 'time_mlp.0.weights' in sd else None
+        if self.fourier_w is None:
+            half = self.dim // 2
+            f = math.log(10000) / (half - 1)
+            self.freq = torch.exp(torch.arange(half) * -f).to(dev)
         self.t_w1, self.t_b1 = f32('time_mlp.1.weight').t().contiguous(), f32('time_mlp.1.bias')
         self.t_w2, self.t_b2 = f32('time_mlp.3.weight').t().contiguous(), f32('time_mlp.3.bias')
         if self.has_classes:
@@ -242,7 +245,7 @@ class UnetEngine:
         B = time.shape[0]
         td = self.t_w2.shape[1]
         cond = torch.empty((reps * B, self.emb_dim), device=time.device, dtype=torch.float32)
-        se = ops.sinusoidal_embed(time, self.freq)
+        se = ops.fourier_embed(time, self.fourier_w) if self.fourier_w is not None else ops.sinusoidal_embed(time, self.freq)
         hmid = ops.linear(se, self.t_w1, self.t_b1, act_out='gelu')
         for r in range(reps):
             ops.linear(hmid, self.t_w2, self.t_b2, out=cond[r * B:(r + 1) * B, :td])

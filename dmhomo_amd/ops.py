@@ -329,6 +329,14 @@ def sinusoidal_embed(t, freq):
     return out
 
 
+def fourier_embed(t, weights):
+    """RandomOrLearnedSinusoidalPosEmb CFG:185-190: (R,) int64, (half,) -> (R, 2*half + 1)"""
+    R, half = t.shape[0], weights.shape[0]
+    out = _empty((R, 2 * half + 1), weights)
+    call('dmh_fourier_embed', ptr(t, torch.int64), ptr(weights), ptr(out), R, half)
+    return out
+
+
 def class_embed(classes, keep, table, null_emb):
     R, dim = classes.shape[0], table.shape[1]
     out = _empty((R, dim), table)
@@ -532,7 +540,11 @@ def flow_to_image(flow, max_flow=256.):
     return rgb
 
 
-def flow_warp(x, flow, want_indices=False):
+FLOW_WARP_PAD = {'border': 0, 'zeros': 1, 'reflection': 2}
+FLOW_WARP_MODE = {'bilinear': 0, 'nearest': 1}
+
+
+def flow_warp(x, flow, want_indices=False, pad='border', mode='bilinear'):
     B, Cc, H, W = x.shape
     assert flow.shape == (B, 2, H, W)
     out = torch.empty_like(x)
@@ -540,7 +552,8 @@ def flow_warp(x, flow, want_indices=False):
     if want_indices:
         x0 = torch.empty((B, H, W), device=x.device, dtype=torch.int32)
         y0 = torch.empty((B, H, W), device=x.device, dtype=torch.int32)
-    call('dmh_flow_warp', ptr(x), ptr(flow), ptr(out), ptr(x0, torch.int32), ptr(y0, torch.int32), B, Cc, H, W)
+    call('dmh_flow_warp', ptr(x), ptr(flow), ptr(out), ptr(x0, torch.int32), ptr(y0, torch.int32), B, Cc, H, W,
+         FLOW_WARP_PAD[pad], FLOW_WARP_MODE[mode])
     return (out, x0, y0) if want_indices else out
 
 

@@ -237,6 +237,9 @@ int dmh_attention(const float* qkv, float* out, int B, int n, float scale, const
  * ------------------------------------------------------------------------------------- */
 /* N7  SinusoidalPosEmb, CFG:165-172: out[r] = (sin(t_r*f), cos(t_r*f)); freq[dim/2] fp32 table */
 int dmh_sinusoidal_embed(const int64_t* t, const float* freq, float* out, int R, int dim, void* stream);
+/* RandomOrLearnedSinusoidalPosEmb, CFG:175-190 [DDP:179-195] (Unet(learned_sinusoidal_cond / random_fourier_features)):
+ * out[r] = (t_r, sin(t_r*w_i*2*pi) i < half, cos(t_r*w_i*2*pi) i < half), out [R][2*half + 1]; weights [half] */
+int dmh_fourier_embed(const int64_t* t, const float* weights, float* out, int R, int half, void* stream);
 /* N8  classes_emb lookup + null swap, CFG:419-425: keep==NULL keeps every row; table [num_classes][dim] — a kept class id
  * outside [0, num_classes) yields a NaN row (device data: it cannot be refused at launch) */
 int dmh_class_embed(const int64_t* classes, const uint8_t* keep, const float* table, const float* null_emb,
@@ -342,10 +345,12 @@ int dmh_homography_flow(const double* Hm, float* flow, float* rgb, int B, int H,
                         void* stream);
 /* G3 alone: flow NCHW [B][2][HW] -> rgb NCHW [B][3][HW] (flow_to_image DDP:1471-1486) */
 int dmh_flow_to_image(const float* flow, float* rgb, int B, int HW, float max_flow, void* stream);
-/* G4  flow_warp DDP:1262-1299 (bilinear, border, align_corners=True); x/out NCHW [B][C][H][W], flow [B][2][H][W].
- * x0/y0 (NULL or int32 [B][H][W]) receive the top-left corner indices (bit-exact contract). */
+/* G4  flow_warp DDP:1262-1299 (grid_sample, align_corners=True); x/out NCHW [B][C][H][W], flow [B][2][H][W].
+ * pad: 0 'border' (the reference's default), 1 'zeros', 2 'reflection'; mode: 0 'bilinear' (default), 1 'nearest' — the
+ * values flow_warp forwards to grid_sample's padding_mode / mode (DDP:1262,1270-1274).
+ * x0/y0 (NULL or int32 [B][H][W]; pad == 0 && mode == 0 only) receive the top-left corner indices (bit-exact contract). */
 int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, int32_t* y0, int B, int C, int H,
-                  int W, void* stream);
+                  int W, int pad, int mode, void* stream);
 /* get_grid DDP:1558-1574: out (B,2,H,W) fp32 = (x + start, y + start) of every pixel */
 int dmh_pixel_grid(float* out, int B, int H, int W, float start, void* stream);
 /* norm_grid DDP:1292-1299: v (B,2,H,W) -> out (B,H,W,2) = (2.0*v_x/(W-1) - 1.0, 2.0*v_y/(H-1) - 1.0), fp32, that op order */

@@ -137,6 +137,47 @@ def flow_warp(x, flow12):
     return acc
 
 
+def flow_warp_general(x, flow12, pad='border', mode='bilinear'):
+    """flow_warp(x, flow12, pad, mode), DDP:1262-1280, for the other values it forwards to F.grid_sample
+    (align_corners=True): pad 'border' | 'zeros' | 'reflection', mode 'bilinear' | 'nearest'.  Coordinates as warp_coords
+    up to the padding rule (ATen/native/GridSampler.h: reflect_coordinates(in, 0, 2 (size - 1)) then clip_coordinates for
+    'reflection'; no clip for 'zeros', whose taps outside the image read 0); 'nearest' rounds ties to even (nearbyint)."""
+    B, C, H, W = x.shape
+    dt = flow12.dtype
+    xs = torch.arange(0, W).repeat(B, H, 1).to(dt)
+    ys = torch.arange(0, H).repeat(B, W, 1).transpose(1, 2).to(dt)
+    gx = 2.0 * (xs + flow12[:, 0]) / (W - 1) - 1.0
+    gy = 2.0 * (ys + flow12[:, 1]) / (H - 1) - 1.0
+
+    def coord(g, size):
+        i = (g + 1) * torch.tensor((size - 1) / 2, dtype=dt)
+        if pad == 'reflection':
+            span = torch.tensor(float(size - 1), dtype=dt)
+            a = i.abs()
+            extra = torch.fmod(a, span)
+            flips = torch.floor(a / span)
+            i = torch.where(torch.fmod(flips, 2) == 0, extra, span - extra)
+        if pad != 'zeros':
+            i = i.clamp(min=0).clamp(max=size - 1)
+        return i
+    ix, iy = coord(gx, W), coord(gy, H)
+    flat = x.reshape(B, C, H * W)
+    zero = torch.zeros((), dtype=x.dtype)
+
+    def tap(fx, fy):
+        ok = (fx >= 0) & (fx <= W - 1) & (fy >= 0) & (fy <= H - 1)
+        idx = (fy.clamp(0, H - 1).long() * W + fx.clamp(0, W - 1).long()).reshape(B, 1, H * W).expand(B, C, H * W)
+        return torch.where(ok[:, None], flat.gather(2, idx).reshape(B, C, H, W), zero)
+    if mode == 'nearest':
+        return tap(torch.round(ix), torch.round(iy))           # torch.round: half to even, as nearbyint
+    x0, y0 = ix.floor(), iy.floor()
+    w, e, n, s_ = ix - x0, (x0 + 1) - ix, iy - y0, (y0 + 1) - iy
+    acc = tap(x0, y0) * (s_ * e)[:, None]
+    for val, wt in ((tap(x0 + 1, y0), s_ * w), (tap(x0, y0 + 1), n * e), (tap(x0 + 1, y0 + 1), n * w)):
+        acc = (val.double() * wt[:, None].double() + acc.double()).to(x.dtype)   # one fma per tap, as flow_warp above
+    return acc
+
+
 # ------------------------------------------------------------------ G5
 def dlt_system(flow):
     """rows of the DLT system of DLT_solve, DDP:1612-1637, for one H per sample:

@@ -134,9 +134,21 @@ def sinusoidal_pos_emb(t, dim):
     return torch.cat((e.sin(), e.cos()), dim=-1)
 
 
+def random_or_learned_pos_emb(t, weights):
+    """RandomOrLearnedSinusoidalPosEmb.forward, CFG:185-190 [DDP:190-195]: cat(t, sin(t w 2 pi), cos(t w 2 pi)); ``t`` int64
+    (B,), ``weights`` (half,) — the op order of the reference (x * w, * 2, * math.pi) is kept."""
+    x = t[:, None]
+    freqs = x * weights[None, :] * 2 * math.pi
+    return torch.cat((x, torch.cat((freqs.sin(), freqs.cos()), dim=-1)), dim=-1)
+
+
 def time_mlp(sd, t, dim):
-    """time_mlp = SinusoidalPosEmb -> Linear -> GELU(erf) -> Linear, CFG:353."""
-    e = sinusoidal_pos_emb(t, dim)
+    """time_mlp = SinusoidalPosEmb (or, with ``time_mlp.0.weights`` in the state_dict, RandomOrLearnedSinusoidalPosEmb:
+    CFG:346-351) -> Linear -> GELU(erf) -> Linear, CFG:353."""
+    if 'time_mlp.0.weights' in sd:
+        e = random_or_learned_pos_emb(t, sd['time_mlp.0.weights'])
+    else:
+        e = sinusoidal_pos_emb(t, dim)
     e = F.linear(e, sd['time_mlp.1.weight'], sd['time_mlp.1.bias'])
     e = F.gelu(e)
     return F.linear(e, sd['time_mlp.3.weight'], sd['time_mlp.3.bias'])

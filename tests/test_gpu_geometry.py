@@ -127,3 +127,31 @@ def test_dlt_recovers_homographies_of_any_strength():
         err = np.abs(got - Hs).max()
         print(f'[parity] DLT round trip at {S}x{S}: max |H - H_true| = {err:.2e}')
         assert err < 8e-5        # measured 7.5e-6: the flow is fp32 (1e-7 relative on coordinates up to 128) and w' carries the reference's + 1e-6
+
+
+@pytest.mark.parametrize('pad', ['border', 'zeros', 'reflection'])
+@pytest.mark.parametrize('mode', ['bilinear', 'nearest'])
+def test_flow_warp_padding_and_mode_variants(golden_dir, pad, mode):
+    """flow_warp(x, flow, pad, mode) DDP:1262-1280 beyond its defaults, as it forwards them to F.grid_sample: the reference's
+    outputs (tests/golden/make_golden_r5.py: targets outside the image, half-pixel ties) — bit for bit for every combination
+    but 'reflection' (fmodf of the reflected coordinate: <= 1e-6) — and a fuzz against the oracle's explicit taps"""
+    from dmhomo_amd import ddpm
+    r5 = {k: v for k, v in np.load(os.path.join(golden_dir, 'r5.npz')).items()}
+    got = ddpm.flow_warp(T(r5['warp.x']).to(dev()), T(r5['warp.flow']).to(dev()), pad=pad, mode=mode).cpu()
+    want = T(r5[f'warp.{pad}.{mode}'])
+    report(f'warp {pad} {mode}', got, want)
+    if pad == 'reflection':
+        assert float((got - want).abs().max()) <= 1e-6
+    else:
+        assert torch.equal(got, want)
+    gen = torch.Generator().manual_seed(77)
+    for H, W, mag in ((7, 9, 3.0), (33, 17, 40.0), (2, 2, 5.0)):
+        img = torch.randn(2, 3, H, W, generator=gen)
+        flow = (torch.rand(2, 2, H, W, generator=gen) * 2 - 1) * mag
+        flow[:, :, 0, :] = flow[:, :, 0, :].round() + 0.5
+        got = ddpm.flow_warp(img.to(dev()), flow.to(dev()), pad=pad, mode=mode).cpu()
+        ref = OG.flow_warp_general(img, flow, pad, mode)
+        err = float((got - ref).abs().max())
+        assert err <= (1e-5 if pad == 'reflection' else 0.0), (pad, mode, H, W, err)
+    with pytest.raises(NotImplementedError):
+        ddpm.flow_warp(img.to(dev()), flow.to(dev()), mode='bicubic')

@@ -754,3 +754,30 @@ def test_ddp_interpolate_vs_golden(golden_dir):
                                  objective='pred_noise', rng=OD.ReplayRng(draws))
     d.rng = ReplayDeviceRng(draws)
     close('interpolate t=6 vs oracle', d.interpolate(x1, x2, t=6, lam=0.7).cpu(), ref, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize('tag,kw', [('learned', dict(learned_sinusoidal_cond=True)), ('random', dict(random_fourier_features=True)),
+                                    ('learned8', dict(learned_sinusoidal_cond=True, learned_sinusoidal_dim=8))])
+def test_unet_cfg_learned_sinusoidal_vs_golden(golden_dir, tag, kw):
+    """Unet(learned_sinusoidal_cond=True / random_fourier_features=True) (RandomOrLearnedSinusoidalPosEmb, CFG:175-190,
+    344-353): a bare Unet.forward caller gets the reference's numbers (GaussianDiffusion refuses such a model, CFG:514-515 —
+    and so does ours); goldens from tests/golden/make_golden_r5.py"""
+    from dmhomo_amd import cfg
+    gd = load(golden_dir, 'r5')
+    m, sd = make_cfg(8, **kw)
+    assert 'time_mlp.0.weights' in sd and m.random_or_learned_sinusoidal_cond
+    x, rf, mk, t = (g(T(gd['cfg.' + k])) for k in ('x', 'rf', 'mk', 't'))
+    c = g(torch.zeros(x.shape[0], dtype=torch.long))
+    close_rel(f'cfg {tag} keep', m(x, t, c, rf, mk, cond_drop_prob=0.).cpu(), T(gd[f'cfg.{tag}.keep']), OUT_REL)
+    close_rel(f'cfg {tag} drop', m(x, t, c, rf, mk, cond_drop_prob=1.).cpu(), T(gd[f'cfg.{tag}.drop']), OUT_REL)
+    with pytest.raises(AssertionError):
+        cfg.GaussianDiffusion(m, image_size=32, timesteps=10)
+
+
+def test_unet_ddp_learned_sinusoidal_vs_golden(golden_dir):
+    gd = load(golden_dir, 'r5')
+    from dmhomo_amd import ddpm
+    m = ddpm.Unet(dim=8, dim_mults=(1, 2, 4, 8), channels=3, learned_sinusoidal_cond=True)
+    m.load_state_dict(det_state_dict(shapes_of(m), 1))
+    m = m.to(dev())
+    close_rel('ddp learned', m(g(T(gd['ddp.x'])), g(T(gd['cfg.t']))).cpu(), T(gd['ddp.learned']), OUT_REL)

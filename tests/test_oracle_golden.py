@@ -318,3 +318,47 @@ def test_philox_known_answers():
     assert abs(z.mean()) < 1e-2 and abs(z.std() - 1) < 1e-2
     u = R.uniform(1, range(4096), 1, 4)
     assert u.min() >= 0 and u.max() < 1 and abs(u.mean() - 0.5) < 1e-2
+
+
+# ------------------------------------------------------------------ round 5 fixtures (tests/golden/make_golden_r5.py)
+@pytest.mark.parametrize('tag,kw', [('learned', dict(learned_sinusoidal_cond=True)), ('random', dict(random_fourier_features=True)),
+                                    ('learned8', dict(learned_sinusoidal_cond=True, learned_sinusoidal_dim=8))])
+def test_unet_cfg_learned_sinusoidal(golden_dir, tag, kw):
+    """RandomOrLearnedSinusoidalPosEmb (CFG:175-190, 344-353): the oracle's forward on a state_dict that carries
+    ``time_mlp.0.weights`` against the reference's outputs; the product's holder offers the reference's keys / shapes"""
+    from dmhomo_amd import cfg
+    from detweights import shapes_of
+    gd = load(golden_dir, 'r5')
+    m = cfg.Unet(dim=8, dim_mults=(1, 2, 4, 8), channels=6, num_classes=1, **kw)
+    half = kw.get('learned_sinusoidal_dim', 16) // 2
+    assert m.random_or_learned_sinusoidal_cond and tuple(m.time_mlp[0].weights.shape) == (half,)
+    assert m.time_mlp[0].weights.requires_grad == (tag != 'random') and m.time_mlp[1].in_features == 2 * half + 1
+    sd = det_state_dict(shapes_of(m))
+    x, rf, mk, t = (T(gd['cfg.' + k]) for k in ('x', 'rf', 'mk', 't'))
+    c = torch.zeros(x.shape[0], dtype=torch.long)
+    with torch.no_grad():
+        close(OU.cfg_unet_forward(sd, x, t, c, rf, mk, None), gd[f'cfg.{tag}.keep'])
+        close(OU.cfg_unet_forward(sd, x, t, c, rf, mk, torch.zeros(x.shape[0], dtype=torch.bool)), gd[f'cfg.{tag}.drop'])
+
+
+def test_unet_ddp_learned_sinusoidal(golden_dir):
+    from dmhomo_amd import ddpm
+    from detweights import shapes_of
+    gd = load(golden_dir, 'r5')
+    m = ddpm.Unet(dim=8, dim_mults=(1, 2, 4, 8), channels=3, learned_sinusoidal_cond=True)
+    sd = det_state_dict(shapes_of(m), 1)
+    with torch.no_grad():
+        close(OU.ddp_unet_forward(sd, T(gd['ddp.x']), T(gd['cfg.t'])), gd['ddp.learned'])
+
+
+@pytest.mark.parametrize('pad', ['border', 'zeros', 'reflection'])
+@pytest.mark.parametrize('mode', ['bilinear', 'nearest'])
+def test_flow_warp_padding_and_mode_variants(golden_dir, pad, mode):
+    """flow_warp(x, flow, pad, mode) DDP:1262-1280 beyond its defaults: the oracle's explicit taps against the reference's
+    F.grid_sample outputs (targets outside the image, half-pixel ties)"""
+    gd = load(golden_dir, 'r5')
+    got = OG.flow_warp_general(T(gd['warp.x']), T(gd['warp.flow']), pad, mode)
+    want = T(gd[f'warp.{pad}.{mode}'])
+    if pad == 'border' and mode == 'bilinear':
+        assert torch.equal(OG.flow_warp(T(gd['warp.x']), T(gd['warp.flow'])), want)        # the pinned default form
+    assert torch.equal(got, want) or float((got - want).abs().max()) <= 1e-6, float((got - want).abs().max())
