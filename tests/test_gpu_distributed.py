@@ -183,7 +183,8 @@ def test_dgm_sample_script_end_to_end(tmp_path, ranks):
                 recs.extend(got)
             for rec in recs:
                 assert rec['imgs'].dtype == np.uint8 and rec['imgs'].shape == (bs, 6, S, S)
-                assert rec['homos'].dtype == np.float64 and rec['homos'].shape == (bs, 3, 3)
+                # (saveTrainPair squeezes the homographies, DDP:1675: a one-sample batch gives (3, 3))
+                assert rec['homos'].dtype == np.float64 and rec['homos'].shape == ((bs, 3, 3) if bs > 1 else (3, 3))
             out[rk] = recs
         return out
 
