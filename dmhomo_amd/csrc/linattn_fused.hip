@@ -28,8 +28,53 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 #define LA_PART (32 + 32 + 1024)  // per (b, split, head): max[32], sum[32], ctx[32][32]  (as attention.hip)
 
+// Diagnostic builds only (make stamps; tools/la_ablate.py -> profiles/r05_linattn_ablation.txt): pieces of the two passes
+// switched off by a device word, so that the time each one is worth is MEASURED before anything is rebuilt around it.
+//   bit 0  the second fp16 piece of every split is not formed (cvt only: the split's fma_mix / cvt pairs are gone)
+//   bit 1  no exponentials (the softmax arguments pass through unchanged)
+//   bit 2  pass 2: no LayerNorm + residual + store behind the head exchange
+//   bit 3  every load of x / statistics comes from the sample's first pixels (one cached line: no HBM stream)
+//   bit 4  no projection MFMAs (staging, softmax, products and stores stay)
+// The product build compiles every LA_ABL(...) to 0.
+#ifdef DMH_STAMPS
+__device__ int g_la_ablate = 0;
+extern "C" int dmh_la_set_ablate(int v) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_la_ablate), &v, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+#define LA_ABL_LOAD() const int la_abl = g_la_ablate
+#define LA_ABL(bit) ((la_abl >> (bit)) & 1)
+#else
+#define LA_ABL_LOAD() constexpr int la_abl = 0
+#define LA_ABL(bit) 0
+#endif
+
 namespace {
 constexpr int KC = 32;      // channels per chunk = K of one MFMA
+
+// the split of common.h, or (diagnostic bit 0) its first half only
+__device__ __forceinline__ void la_split2(float x0, float x1, float s, unsigned& h, unsigned& r, int cheap) {
+  if (cheap) {
+    float t0 = x0 * s, t1 = x1 * s;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(t0), "v"(t1));
+    r = 0u;
+  } else {
+    dmh_split2(x0, x1, s, h, r);
+  }
+}
+__device__ __forceinline__ void la_split8(const float (&x)[8], float s, dmh_half8& h, dmh_half8& r, int cheap) {
+  if (cheap) {
+    uint4 hh, rr = make_uint4(0u, 0u, 0u, 0u);
+    la_split2(x[0], x[1], s, hh.x, rr.x, 1);
+    la_split2(x[2], x[3], s, hh.y, rr.y, 1);
+    la_split2(x[4], x[5], s, hh.z, rr.z, 1);
+    la_split2(x[6], x[7], s, hh.w, rr.w, 1);
+    asm volatile("s_nop 3" : "+v"(hh.x), "+v"(hh.y), "+v"(hh.z), "+v"(hh.w));
+    h = __builtin_bit_cast(dmh_half8, hh);
+    r = __builtin_bit_cast(dmh_half8, rr);
+  } else {
+    dmh_split8(x, s, h, r);
+  }
+}
 constexpr int PITCH = 160;  // LDS bytes per staged pixel (conv_f16x3.hip: conflict-free ds_read_b128)
 constexpr int TP = 64;      // pixels per sub-tile
 constexpr int TILE_BYTES = TP * PITCH;
@@ -57,6 +102,7 @@ struct Stager {
   float4 gq;
   float sc, inv_sc;
   int seq = 0;  // staged chunks so far (selects the LDS tile; keeps alternating across sub-tiles)
+  int abl = 0;  // diagnostic builds: the LA_ABL bits (0 in the product)
 
   // every wave derives the same scale from g: bound = sqrt(C) * max|g|, bound * sc in [2^14, 2^15)
   __device__ __forceinline__ void init_scale() {
@@ -75,7 +121,7 @@ struct Stager {
     for (int i = 0; i < 2; ++i) {
       const int pix = p0 + pix0 + 32 * i;
       ok[i] = pix < n;
-      const int pc = ok[i] ? pix : n - 1;
+      const int pc = (abl & 8) ? pix0 : (ok[i] ? pix : n - 1);
       mean[i] = stats_b[(size_t)pc * 2 + 0];
       rstd[i] = stats_b[(size_t)pc * 2 + 1];
     }
@@ -84,7 +130,7 @@ struct Stager {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int pix = p0 + pix0 + 32 * i;
-      const int pc = pix < n ? pix : n - 1;  // clamped address, masked value
+      const int pc = (abl & 8) ? pix0 : (pix < n ? pix : n - 1);  // clamped address, masked value
       v[i] = ld4(xb + (size_t)pc * C + ch * KC + c4 * 4);
     }
     gq = ld4(g + ch * KC + c4 * 4);
@@ -106,8 +152,8 @@ struct Stager {
         x = make_float4(0.f, 0.f, 0.f, 0.f);
       }
       uint2 h1, h2;                                        // second piece stored unscaled (conv_f16x3.hip)
-      dmh_split2(x.x, x.y, sc, h1.x, h2.x);
-      dmh_split2(x.z, x.w, sc, h1.y, h2.y);
+      la_split2(x.x, x.y, sc, h1.x, h2.x, abl & 1);
+      la_split2(x.z, x.w, sc, h1.y, h2.y, abl & 1);
       unsigned char* dst = tile + (pix0 + 32 * i) * PITCH + c4 * 8;
       *reinterpret_cast<uint2*>(dst) = h1;
       *reinterpret_cast<uint2*>(dst + 64) = h2;
@@ -158,6 +204,7 @@ struct RingStager {
   float4 gq[2];
   float sc, inv_sc;
   int seq = 0;
+  int abl = 0;  // diagnostic builds: the LA_ABL bits (0 in the product)
 
   __device__ __forceinline__ void init(const float* x_b, const float* stats_b_, const float* g, int n_, int p0w_, int tiles,
                                        unsigned char* ring_) {
@@ -194,7 +241,7 @@ struct RingStager {
   }
   // sub-tile t (< U): its statistics, then the wave's four pieces (16 pixels x 256 B)
   __device__ __forceinline__ void issue_unit(int t) {
-    const int p0 = p0w + t * TP;
+    const int p0 = (abl & 8) ? 0 : p0w + t * TP;
     const int fl = min((p0 + wave * 16) * 2 + (lane & 31), 2 * n - 1);        // clamped; pixels beyond n are masked later
     if (lane < 32) glds(stats_b + fl, ring_lds + RD * UNIT + (t % STATS_SLOTS) * (TP * 8) + wave * 128, false);
 #pragma unroll
@@ -238,8 +285,8 @@ struct RingStager {
           x = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         uint2 h1, h2;
-        dmh_split2(x.x, x.y, sc, h1.x, h2.x);
-        dmh_split2(x.z, x.w, sc, h1.y, h2.y);
+        la_split2(x.x, x.y, sc, h1.x, h2.x, abl & 1);
+        la_split2(x.z, x.w, sc, h1.y, h2.y, abl & 1);
         unsigned char* dst = set + ch * TILE_BYTES + (pix0 + 32 * i) * PITCH + c4 * 8;
         *reinterpret_cast<uint2*>(dst) = h1;
         *reinterpret_cast<uint2*>(dst + 64) = h2;
@@ -283,7 +330,9 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
   const int l15 = lane & 15, kg = lane >> 4;
   const int nch = C / KC;
 
+  LA_ABL_LOAD();
   Stager<2> st;
+  st.abl = la_abl;
   st.xb = x + (size_t)b * n * C;
   st.g = g;
   st.C = C;
@@ -340,9 +389,13 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
 #define LA_TERM(pl, bexpr)                                                                          \
   _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) \
       acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
+      if (!LA_ABL(4)) {
       LA_TERM(1, __builtin_bit_cast(half8, bq[nb * 2]))
       LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2 + 1]))
       LA_TERM(0, __builtin_bit_cast(half8, bq[nb * 2]))
+      } else {
+        acc[0][0][0] += (float)a[0][0][0] + (float)a[3][1][7];   // (keeps the fragment reads alive)
+      }
 #undef LA_TERM
     };
     if (RES) {
@@ -416,10 +469,11 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
         float pv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          pv[j] = __builtin_amdgcn_exp2f(acc[2 * ks + (j >> 2)][db][j & 3] - m_new[db]);  // 2^-inf = 0 for pixels beyond n
+          const float arg = acc[2 * ks + (j >> 2)][db][j & 3] - m_new[db];
+          pv[j] = LA_ABL(1) ? arg : __builtin_amdgcn_exp2f(arg);  // 2^-inf = 0 for pixels beyond n
           s += pv[j];
         }
-        dmh_split8(pv, 1024.f, p1[db][ks], p2[db][ks]);
+        la_split8(pv, 1024.f, p1[db][ks], p2[db][ks], LA_ABL(0));
       }
       s = rows_sum(s);
       s_run[db] += s;
@@ -451,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
         float vv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) vv[j] = acc[2 * ks + (j >> 2)][2 + eb][j & 3];
-        dmh_split8(vv, scv, v1[eb][ks], v2[eb][ks]);
+        la_split8(vv, scv, v1[eb][ks], v2[eb][ks], LA_ABL(0));
       }
     float4v t[2][2];  // [eb][db]: four independent chains, term by term; A = v (rows e), B = p (columns d)
 #pragma unroll
@@ -515,7 +569,9 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
   const int l15 = lane & 15, kg = lane >> 4;
 
+  LA_ABL_LOAD();
   RingStager st;
+  st.abl = la_abl;
   st.init(x + (size_t)b * n * C, stats + (size_t)b * n * 2, g, n, sp * tiles * TP, tiles, smem + 4 * TILE_BYTES);
   const int nch = 2;
 
@@ -589,9 +645,13 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
 #define LA_TERM(pl, bexpr)                                                                          \
   _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) \
       acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
+      if (!LA_ABL(4)) {
       LA_TERM(1, __builtin_bit_cast(half8, wres[ch][nb * 2]))
       LA_TERM(0, __builtin_bit_cast(half8, wres[ch][nb * 2 + 1]))
       LA_TERM(0, __builtin_bit_cast(half8, wres[ch][nb * 2]))
+      } else {
+        acc[0][0][0] += (float)a[0][0][0] + (float)a[3][1][7];   // (keeps the fragment reads alive)
+      }
 #undef LA_TERM
     }
     KSTAMP(2)  // fragment reads + 96 projection MFMAs
@@ -644,10 +704,11 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
         float pv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          pv[j] = __builtin_amdgcn_exp2f(fmaf(acc[2 * ks + (j >> 2)][db][j & 3], kks[db], -m_new[db]));  // 2^-inf = 0 beyond n
+          const float arg = fmaf(acc[2 * ks + (j >> 2)][db][j & 3], kks[db], -m_new[db]);
+          pv[j] = LA_ABL(1) ? arg : __builtin_amdgcn_exp2f(arg);  // 2^-inf = 0 beyond n
           s += pv[j];
         }
-        dmh_split8(pv, 1024.f, p1[db][ks], p2[db][ks]);
+        la_split8(pv, 1024.f, p1[db][ks], p2[db][ks], LA_ABL(0));
       }
       s = rows_sum(s);
       s_run[db] += s;
@@ -684,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
         float vv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) vv[j] = acc[2 * ks + (j >> 2)][2 + eb][j & 3];
-        dmh_split8(vv, sv, v1[eb][ks], v2[eb][ks]);
+        la_split8(vv, sv, v1[eb][ks], v2[eb][ks], LA_ABL(0));
       }
     }
     KSTAMP(4)  // v: block maximum, split
@@ -790,7 +851,9 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
   const int l15 = lane & 15, kg = lane >> 4;
   const int nch = C / KC;
 
+  LA_ABL_LOAD();
   Stager<NBUF> st;
+  st.abl = la_abl;
   st.xb = x + (size_t)b * n * C;
   st.g = g;
   st.C = C;
@@ -903,9 +966,13 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
 #define LA_TERM(aexpr, pl)                                                                           \
   _Pragma("unroll") for (int db = 0; db < 2; ++db) _Pragma("unroll") for (int nbn = 0; nbn < 4; ++nbn) \
       acc[db][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aexpr, xb[nbn][pl], acc[db][nbn], 0, 0, 0);
+      if (!LA_ABL(4)) {
       LA_TERM(__builtin_bit_cast(half8, aq[db * 2]), 1)
       LA_TERM(__builtin_bit_cast(half8, aq[db * 2 + 1]), 0)
       LA_TERM(__builtin_bit_cast(half8, aq[db * 2]), 0)
+      } else {
+        acc[0][0][0] += (float)xb[0][0][0] + (float)xb[3][1][7];   // (keeps the fragment reads alive)
+      }
 #undef LA_TERM
     };
     if (FUSE) {  // C == 64: both chunks' q fragments stay in registers for the whole workgroup
@@ -950,7 +1017,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(acc[db][nbn][r] - m);  // v_exp_f32: ~1e-7 relative, as in pass 1
+          const float e = LA_ABL(1) ? acc[db][nbn][r] - m : __builtin_amdgcn_exp2f(acc[db][nbn][r] - m);  // v_exp_f32: ~1e-7 relative, as in pass 1
           acc[db][nbn][r] = e;
           s += e;
         }
@@ -970,7 +1037,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
       float e8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) e8[j] = acc[j >> 2][nbn][j & 3];
-      dmh_split8(e8, rsv[nbn], q1[nbn], q2[nbn]);
+      la_split8(e8, rsv[nbn], q1[nbn], q2[nbn], LA_ABL(0));
     }
     // eight independent accumulation chains, term by term (a chain's MFMAs are eight instructions apart)
     float4v ot[4][2];
@@ -1006,7 +1073,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
         float o8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = ot[nbn][j >> 2][j & 3];
-        dmh_split8(o8, mo, h1[nbn], h2[nbn]);
+        la_split8(o8, mo, h1[nbn], h2[nbn], LA_ABL(0));
       }
 #pragma unroll
       for (int nbn = 0; nbn < 4; ++nbn)
@@ -1049,7 +1116,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
       float4 xr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int pix = min(p0 + (tid >> 4) + 16 * i, n - 1);
+        const int pix = LA_ABL(3) ? (tid >> 4) : min(p0 + (tid >> 4) + 16 * i, n - 1);
         xr[i] = ld4(st.xb + (size_t)pix * 64 + quad * 4);
       }
       float4 oq = ld4(fo.osc_o + quad * 4);
@@ -1075,6 +1142,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
       // passes, as chan_layernorm_kernel), * g, + x
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        if (LA_ABL(2)) break;
         const int pl = (tid >> 4) + 16 * i;  // pixel of the sub-tile
         const float* yp = yx + pl * YP + quad * 4;
         const float4 y0 = ld4(yp), y1 = ld4(yp + TP * YP), y2 = ld4(yp + 2 * TP * YP), y3 = ld4(yp + 3 * TP * YP);
