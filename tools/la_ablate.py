@@ -81,14 +81,25 @@ def run(C, H, B, fuse):
     print(f'C={C} {H}x{H} B={B}: pass 1 = linattn_kv{"_ring" if C == 64 else ""}_kernel (algorithmic {alg1 / 1e6:.0f} MB), '
           f'pass 2 = linattn_qo_kernel<{"true" if fuse else "false"}> (algorithmic {alg2 / 1e6:.0f} MB; '
           f'{"x twice (staging + residual), y once" if fuse else "x once, out once"})')
-    base = None
+    # three round-robin sweeps over the cases (clock / power state drifts over a run: a case is compared with its neighbours in
+    # time), median per case; a block of untimed launches first
+    for i in range(40):
+        p1(i % nrot)
+        p2(i % nrot)
+    res = {bits: ([], []) for bits, _ in CASES}
+    for sweep in range(3):
+        for bits, _ in CASES:
+            assert h.dmh_la_set_ablate(bits) == 0
+            res[bits][0].append(timed(p1))
+            res[bits][1].append(timed(p2))
+    med = {b: (sorted(v[0])[1], sorted(v[1])[1]) for b, v in res.items()}
+    base = med[0]
     for bits, name in CASES:
-        assert h.dmh_la_set_ablate(bits) == 0
-        t1, t2 = timed(p1), timed(p2)
-        if base is None:
-            base = (t1, t2)
+        t1, t2 = med[bits]
         print(f'  ablate={bits:2d} {name:62s} pass 1 {t1:7.1f} us ({t1 - base[0]:+6.1f})   pass 2 {t2:7.1f} us ({t2 - base[1]:+6.1f})',
               flush=True)
+    print(f'  (spread of the ablate = 0 line over the three sweeps: pass 1 {min(res[0][0]):.1f} .. {max(res[0][0]):.1f} us, '
+          f'pass 2 {min(res[0][1]):.1f} .. {max(res[0][1]):.1f} us)')
     h.dmh_la_set_ablate(0)
     print(f'  HBM time of the algorithmic bytes at 8 TB/s: pass 1 {alg1 / 8e6:.1f} us, pass 2 {alg2 / 8e6:.1f} us')
 
