@@ -295,6 +295,49 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < NLOAD; ++i) issue_one(i);
   __syncthreads();                              // block-maximum slots are zeroed
+#ifdef DMH_STAMPS
+  // diagnostic build only (tools/gn_fold_cost.py, docs/EXPERIMENTS.md R5.4): what a gn_finalize folded into its CONSUMER would
+  // add to the head of every workgroup — 8 KB of per-(tile, group) partials of the sample (any L2-resident 8 KB of it stands
+  // in), reduced in f64 in a fixed order, (a, b) for every input channel into LDS, the barrier that publishes them
+  if (p.ablate & 128) {
+    const float* gs = p.src0 + (size_t)b * p.Hin * p.Win * p.C0;
+    double q1 = 0.0, q2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float2 t2 = *reinterpret_cast<const float2*>(gs + (size_t)(((tid & 31) + 32 * j) * 8 + (tid >> 5)) * 2);
+      q1 += (double)t2.x;
+      q2 += (double)t2.y;
+    }
+    for (int off = 16; off; off >>= 1) {
+      q1 += __shfl_xor(q1, off);
+      q2 += __shfl_xor(q2, off);
+    }
+    const double nn = (double)p.Hin * p.Win * (p.C0 / 8);
+    const double mean = q1 / nn;
+    double var = q2 / nn - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5)), meanf = (float)mean;
+    float* tab = reinterpret_cast<float*>(in_tile);
+    float* gtab = tab + 2 * 768;
+    if ((tid & 31) == 0) {
+      gtab[(tid >> 5) * 2 + 0] = meanf;
+      gtab[(tid >> 5) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    const float* cf = p.in_coef ? p.in_coef + (size_t)b * 2 * p.C0 : p.bias;
+    for (int c = tid; c < p.C0 && c < 768; c += 256) {
+      const int g8 = c / max(p.C0 / 8, 1);
+      const float ga = cf ? cf[c % 64] : 1.f, be = cf ? cf[(c + 32) % 64] : 0.f;   // (gamma, beta, (scale, shift): three more L2 reads)
+      const float aa = gtab[g8 * 2 + 1] * ga;
+      tab[c * 2 + 0] = aa;
+      tab[c * 2 + 1] = be - gtab[g8 * 2 + 0] * aa;
+    }
+    __syncthreads();
+    const float probe = tab[(tid & 63) * 2] + tab[(tid & 63) * 2 + 1];
+    asm volatile("" ::"v"(probe));
+    __syncthreads();                            // (the staging below reuses this LDS: a real fold would own its table)
+  }
+#endif
 
   int e_run = 16;  // biased exponent of the running block maximum (clamped to [16, 254]); uniform
   // DmhConv.in_bound: the producer's GroupNorm statistics bound |a*x + b| >= |SiLU(a*x + b)| for every element of the sample,
