@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void homography_flow_kernel(const double* __re
 // pad: 0 'border' (the reference's default: coordinates clipped to the image), 1 'zeros' (taps outside the image read 0),
 // 2 'reflection' (reflected about the border pixels' centres, then clipped) — grid_sample's padding_mode with
 // align_corners=True (ATen/native/GridSampler.h: clip_coordinates, reflect_coordinates).  mode: 0 'bilinear', 1 'nearest'
-// (nearbyint, ties to even).
+// (nearbyint, ties to even), 2 'bicubic' (cubic convolution, A = -0.75, 4 x 4 taps around floor of the UNPADDED coordinate;
+// the padding rule is applied to every tap index: get_value_bounded).
 __device__ __forceinline__ float gs_reflect(float in, int size) {  // reflect_coordinates(in, 0, 2 * (size - 1))
   if (size <= 1) return 0.f;
   const float span = (float)(size - 1);
@@ -79,11 +80,23 @@ __device__ __forceinline__ float gs_reflect(float in, int size) {  // reflect_co
   const int flips = (int)floorf(in / span);
   return (flips & 1) == 0 ? extra : span - extra;
 }
-__device__ __forceinline__ float gs_coord(float g, int size, int pad) {
-  float i = (g + 1.f) * ((float)(size - 1) / 2.f);
+__device__ __forceinline__ float gs_pad(float i, int size, int pad) {   // compute_coordinates
   if (pad == 2) i = gs_reflect(i, size);
   if (pad != 1) i = fminf((float)(size - 1), fmaxf(i, 0.f));
   return i;
+}
+__device__ __forceinline__ float gs_coord(float g, int size, int pad) {
+  return gs_pad((g + 1.f) * ((float)(size - 1) / 2.f), size, pad);
+}
+// get_cubic_upsample_coefficients (ATen/native/UpSample.h), A = -0.75
+__device__ __forceinline__ void gs_cubic(float t, float (&c)[4]) {
+  const float A = -0.75f;
+  auto c1 = [A](float x) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; };
+  auto c2 = [A](float x) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; };
+  c[0] = c1(t + 1.f);
+  c[1] = c2(t);
+  c[2] = c2(1.f - t);
+  c[3] = c1(2.f - t);
 }
 __global__ __launch_bounds__(256) void flow_warp_general_kernel(const float* __restrict__ x, const float* __restrict__ flow,
                                                                 float* __restrict__ out, int C, int H, int W, int pad, int mode) {
@@ -96,6 +109,29 @@ __global__ __launch_bounds__(256) void flow_warp_general_kernel(const float* __r
   const float vy = (float)yi + flow[((size_t)b * 2 + 1) * hw + p];
   const float gx = 2.0f * vx / (float)(W - 1) - 1.0f;
   const float gy = 2.0f * vy / (float)(H - 1) - 1.0f;
+  if (mode == 2) {
+    const float ux = (gx + 1.f) * ((float)(W - 1) / 2.f), uy = (gy + 1.f) * ((float)(H - 1) / 2.f);   // unnormalize only
+    const float fx0 = floorf(ux), fy0 = floorf(uy);
+    float cx[4], cy[4];
+    gs_cubic(ux - fx0, cx);
+    gs_cubic(uy - fy0, cy);
+    for (int c = 0; c < C; ++c) {
+      const float* xc = x + ((size_t)b * C + c) * hw;
+      float acc = 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const float py = gs_pad(fy0 - 1.f + (float)i, H, pad);
+        float row = 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const float px = gs_pad(fx0 - 1.f + (float)j, W, pad);
+          const bool ok = px >= 0.f && px <= (float)(W - 1) && py >= 0.f && py <= (float)(H - 1);
+          row += (ok ? xc[(size_t)(int)py * W + (int)px] : 0.f) * cx[j];
+        }
+        acc += row * cy[i];
+      }
+      out[((size_t)b * C + c) * hw + p] = acc;
+    }
+    return;
+  }
   const float ix = gs_coord(gx, W, pad), iy = gs_coord(gy, H, pad);
   auto tap = [&](const float* xc, float fx, float fy) -> float {   // within_bounds_2d ? value : 0
     // (a NaN or far-away coordinate compares false / falls outside: 0, as safe_get / the masked gather give)
@@ -287,7 +323,8 @@ extern "C" int dmh_flow_to_image(const float* flow, float* rgb, int B, int HW, f
 extern "C" int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, int32_t* y0, int B, int C,
                              int H, int W, int pad, int mode, void* stream) {
   DMH_REQUIRE(x && flow && out && B > 0 && C > 0 && H > 1 && W > 1, "dmh_flow_warp: bad arguments");
-  DMH_REQUIRE(pad >= 0 && pad <= 2 && mode >= 0 && mode <= 1, "dmh_flow_warp: pad=%d (0 border, 1 zeros, 2 reflection), mode=%d (0 bilinear, 1 nearest)", pad, mode);
+  DMH_REQUIRE(pad >= 0 && pad <= 2 && mode >= 0 && mode <= 2,
+              "dmh_flow_warp: pad=%d (0 border, 1 zeros, 2 reflection), mode=%d (0 bilinear, 1 nearest, 2 bicubic)", pad, mode);
   if (pad != 0 || mode != 0) {
     DMH_REQUIRE(!x0 && !y0, "dmh_flow_warp: the corner indices are an output of the default (border, bilinear) form only");
     hipLaunchKernelGGL(flow_warp_general_kernel, dim3(cdiv(H * W, 256), B), dim3(256), 0, (hipStream_t)stream, x, flow, out, C,

@@ -349,7 +349,8 @@ def DLT_solve(src_p, off_set):
 
 def flow_warp(x, flow12, pad='border', mode='bilinear'):
     """G4, DDP:1262-1280: ``pad`` / ``mode`` are grid_sample's padding_mode / mode (DDP:1270-1274): 'border' | 'zeros' |
-    'reflection' and 'bilinear' | 'nearest' ('bicubic' is not built: no caller in DGM passes anything but the defaults)."""
+    'reflection' and 'bilinear' | 'nearest' | 'bicubic' — every value grid_sample takes for 4-D inputs (no caller in DGM
+    passes anything but the defaults)."""
     if pad not in ops.FLOW_WARP_PAD or mode not in ops.FLOW_WARP_MODE:
         raise NotImplementedError(f"flow_warp(pad={pad!r}, mode={mode!r}): built are pad in {sorted(ops.FLOW_WARP_PAD)} and mode "
                                   f"in {sorted(ops.FLOW_WARP_MODE)} (DDP:1262-1280 forwards both to F.grid_sample)")

@@ -541,7 +541,7 @@ def flow_to_image(flow, max_flow=256.):
 
 
 FLOW_WARP_PAD = {'border': 0, 'zeros': 1, 'reflection': 2}
-FLOW_WARP_MODE = {'bilinear': 0, 'nearest': 1}
+FLOW_WARP_MODE = {'bilinear': 0, 'nearest': 1, 'bicubic': 2}
 
 
 def flow_warp(x, flow, want_indices=False, pad='border', mode='bilinear'):

@@ -346,7 +346,7 @@ int dmh_homography_flow(const double* Hm, float* flow, float* rgb, int B, int H,
 /* G3 alone: flow NCHW [B][2][HW] -> rgb NCHW [B][3][HW] (flow_to_image DDP:1471-1486) */
 int dmh_flow_to_image(const float* flow, float* rgb, int B, int HW, float max_flow, void* stream);
 /* G4  flow_warp DDP:1262-1299 (grid_sample, align_corners=True); x/out NCHW [B][C][H][W], flow [B][2][H][W].
- * pad: 0 'border' (the reference's default), 1 'zeros', 2 'reflection'; mode: 0 'bilinear' (default), 1 'nearest' — the
+ * pad: 0 'border' (the reference's default), 1 'zeros', 2 'reflection'; mode: 0 'bilinear' (default), 1 'nearest', 2 'bicubic' — the
  * values flow_warp forwards to grid_sample's padding_mode / mode (DDP:1262,1270-1274).
  * x0/y0 (NULL or int32 [B][H][W]; pad == 0 && mode == 0 only) receive the top-left corner indices (bit-exact contract). */
 int dmh_flow_warp(const float* x, const float* flow, float* out, int32_t* x0, int32_t* y0, int B, int C, int H,

@@ -139,7 +139,7 @@ def flow_warp(x, flow12):
 
 def flow_warp_general(x, flow12, pad='border', mode='bilinear'):
     """flow_warp(x, flow12, pad, mode), DDP:1262-1280, for the other values it forwards to F.grid_sample
-    (align_corners=True): pad 'border' | 'zeros' | 'reflection', mode 'bilinear' | 'nearest'.  Coordinates as warp_coords
+    (align_corners=True): pad 'border' | 'zeros' | 'reflection', mode 'bilinear' | 'nearest' | 'bicubic'.  Coordinates as warp_coords
     up to the padding rule (ATen/native/GridSampler.h: reflect_coordinates(in, 0, 2 (size - 1)) then clip_coordinates for
     'reflection'; no clip for 'zeros', whose taps outside the image read 0); 'nearest' rounds ties to even (nearbyint)."""
     B, C, H, W = x.shape
@@ -160,9 +160,41 @@ def flow_warp_general(x, flow12, pad='border', mode='bilinear'):
         if pad != 'zeros':
             i = i.clamp(min=0).clamp(max=size - 1)
         return i
-    ix, iy = coord(gx, W), coord(gy, H)
     flat = x.reshape(B, C, H * W)
     zero = torch.zeros((), dtype=x.dtype)
+    if mode == 'bicubic':
+        # cubic convolution (A = -0.75) over the 4 x 4 taps around floor of the UNPADDED coordinate; the padding rule applies
+        # to each tap index (get_value_bounded); rows are interpolated along x first, then along y
+        def pad_idx(i, size):
+            if pad == 'reflection':
+                span = torch.tensor(float(size - 1), dtype=dt)
+                a = i.abs()
+                extra = torch.fmod(a, span)
+                i = torch.where(torch.fmod(torch.floor(a / span), 2) == 0, extra, span - extra)
+            return i if pad == 'zeros' else i.clamp(min=0).clamp(max=size - 1)
+
+        def coeffs(t):
+            A = -0.75
+            c1 = lambda v: ((A * v - 5 * A) * v + 8 * A) * v - 4 * A
+            c2 = lambda v: ((A + 2) * v - (A + 3)) * v * v + 1
+            return [c1(t + 1), c2(t), c2(1 - t), c1(2 - t)]
+        ux = (gx + 1) * torch.tensor((W - 1) / 2, dtype=dt)
+        uy = (gy + 1) * torch.tensor((H - 1) / 2, dtype=dt)
+        x0, y0 = ux.floor(), uy.floor()
+        cx, cy = coeffs(ux - x0), coeffs(uy - y0)
+        acc = torch.zeros_like(x)
+        for i in range(4):
+            py = pad_idx(y0 - 1 + i, H)
+            row = torch.zeros_like(x)
+            for j in range(4):
+                px = pad_idx(x0 - 1 + j, W)
+                ok = (px >= 0) & (px <= W - 1) & (py >= 0) & (py <= H - 1)
+                idx = (py.clamp(0, H - 1).long() * W + px.clamp(0, W - 1).long()).reshape(B, 1, H * W).expand(B, C, H * W)
+                v = torch.where(ok[:, None], flat.gather(2, idx).reshape(B, C, H, W), zero)
+                row = row + v * cx[j][:, None]
+            acc = acc + row * cy[i][:, None]
+        return acc
+    ix, iy = coord(gx, W), coord(gy, H)
 
     def tap(fx, fy):
         ok = (fx >= 0) & (fx <= W - 1) & (fy >= 0) & (fy <= H - 1)

@@ -352,7 +352,7 @@ def test_unet_ddp_learned_sinusoidal(golden_dir):
 
 
 @pytest.mark.parametrize('pad', ['border', 'zeros', 'reflection'])
-@pytest.mark.parametrize('mode', ['bilinear', 'nearest'])
+@pytest.mark.parametrize('mode', ['bilinear', 'nearest', 'bicubic'])
 def test_flow_warp_padding_and_mode_variants(golden_dir, pad, mode):
     """flow_warp(x, flow, pad, mode) DDP:1262-1280 beyond its defaults: the oracle's explicit taps against the reference's
     F.grid_sample outputs (targets outside the image, half-pixel ties)"""
@@ -361,4 +361,5 @@ def test_flow_warp_padding_and_mode_variants(golden_dir, pad, mode):
     want = T(gd[f'warp.{pad}.{mode}'])
     if pad == 'border' and mode == 'bilinear':
         assert torch.equal(OG.flow_warp(T(gd['warp.x']), T(gd['warp.flow'])), want)        # the pinned default form
-    assert torch.equal(got, want) or float((got - want).abs().max()) <= 1e-6, float((got - want).abs().max())
+    tol = 5e-6 if mode == 'bicubic' else 1e-6          # (16 taps: the order of the sums is the vectorised kernel's, not pinned)
+    assert torch.equal(got, want) or float((got - want).abs().max()) <= tol, float((got - want).abs().max())
