@@ -176,3 +176,30 @@ def test_keep_mask_is_the_uniform_draw_compared_on_the_device():
         want = (ORNG.uniform(1234, ids_h, 9)[:, 0] < np.float32(prob)).astype(np.uint8)
         assert np.array_equal(keep.cpu().numpy(), want)
     assert 0 < int(ops.rng_keep_mask(torch.arange(4096, dtype=torch.int64, device=dev()), _state(5), 0.5).sum()) < 4096
+
+
+def test_short_last_batch_draws_the_first_ids():
+    """a loader that keeps its short last batch (dataset.ConditionLoader, like the reference's DataLoader, DDP:1746-1752) hands
+    sample() fewer rows than the generator was keyed for: the draw uses the first n ids (cfg.DeviceRng.ids_for) — bitwise what
+    a generator keyed for exactly those ids draws at the same draw index — also on the captured path; more rows than ids raise"""
+    from dmhomo_amd import cfg
+    from test_gpu_unet import make_cfg
+    m, _ = make_cfg(8)
+    m.cfg_mode = 'streams'
+    d = cfg.GaussianDiffusion(m, image_size=16, timesteps=1000, sampling_timesteps=4, objective='pred_x0').to(dev())
+    rf01, flow, mk, c = (t.to(dev()) for t in _fullsize_inputs(3, 16))
+    for graph in (False, True):
+        d.hip_graph = graph
+        d.rng.key_by_sample(9, range(10, 13), dev())
+        d.sample(c, rf01, flow, mk)
+        short = d.sample(c[:2], rf01[:2].contiguous(), flow[:2].contiguous(), mk[:2].contiguous())[0].clone()
+        d.rng.key_by_sample(9, range(10, 12), dev())
+        d.sample(c[:2], rf01[:2].contiguous(), flow[:2].contiguous(), mk[:2].contiguous())       # (same number of draws as above)
+        want = d.sample(c[:2], rf01[:2].contiguous(), flow[:2].contiguous(), mk[:2].contiguous())[0]
+        assert torch.equal(short, want), graph
+    with pytest.raises(ValueError):
+        d.rng.key_by_sample(9, range(2), dev())
+        d.sample(c, rf01, flow, mk)
+    d.hip_graph = False
+    d.rng.unkey()
+    m.cfg_mode = 'batched'
