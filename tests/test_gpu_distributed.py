@@ -223,3 +223,23 @@ def test_bench_ranks_on_one_gpu(ranks, extra):
     assert d['n_gpus'] == ranks and d['rccl_ranks'] == ranks and d['backend'] == 'gloo' and d['scaling'] == 'weak'
     assert d['config']['global_batch'] == int(extra[1]) * ranks and d['value'] > 0 and d['steps'] == 2
     assert d['variants']['dedup_dropped_rows']['value'] > 0
+
+
+def test_train_bench_eight_ranks_on_one_gpu():
+    """BASELINE configs[3]'s process count: `python bench.py --workload train --gpus 8` (a small model, 2 images per rank, the 8
+    ranks time-sharing the one GPU over gloo) — weights of rank 0 on every rank, forward + backward on the HIP kernels, ONE
+    flat gradient all-reduce per optimiser step, clip + Adam + re-pack — and afterwards every rank holds bit for bit the same
+    parameters"""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(DMH_DIST_BACKEND='gloo', DMH_SHARE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--workload', 'train', '--gpus', '8', '--dim', '8',
+                        '--image_size', '16', '--bs', '2', '--steps', '2', '--warmup', '1'], capture_output=True, text=True,
+                       env=env, cwd=root, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['backend'] == 'gloo' and d['ranks_agree'] is True
+    assert d['value'] > 0 and d['loss'] == d['loss'] and abs(d['loss']) < 1e3          # finite

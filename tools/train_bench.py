@@ -95,6 +95,14 @@ def run(a):
             'loss': float(loss)}
     line.update({'steps': a.steps, 'warmup': a.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                  'dtype': 'f32', 'data': 'synthetic'})
+    if world > 1:
+        # every rank applied the same averaged gradient with the same Adam state: the parameters must agree bit for bit
+        dig = torch.stack([p.detach().double().sum() for p in ts.params.values()]).sum().reshape(1)
+        lo, hi = dig.clone(), dig.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        line['ranks_agree'] = bool(float(lo) == float(hi))
+        line['backend'] = torch.distributed.get_backend()
     if a.torch and rank == 0:
         line['torch_autograd_same_gpu'] = torch_leg(a, dev)
     return line if rank == 0 else None
