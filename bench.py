@@ -32,9 +32,10 @@ Prints ONE JSON line on rank 0, including
                (what an exact-fp32 MFMA kernel could reach at most).  HIP events sit on the launch stream around
                every dmh_conv2d of ONE EXTRA untimed step in batched mode (exclusive per-launch durations: in the
                default 'streams' mode the two CFG passes overlap); the timed region itself carries no events.
-               traffic = HBM bytes per launch of that kernel from the rocprofv3 PMC passes committed under
-               profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate passes) — not measured by this process, and tagged
-               with its source file
+               traffic = HBM bytes per launch of that kernel, MEASURED BY THIS RUN (round 5): two child runs of this script
+               under `rocprofv3 --pmc` (FETCH_SIZE x2, WRITE_SIZE: separate passes) after the timed region; the committed
+               figure of profiles/ stays beside it (`traffic_committed`, `traffic_vs_committed`); `--no-traffic`, N > 1 or a
+               failing profiler fall back to the committed figure, tagged with its source file
   cpu_baseline the oracle (a port of the reference's CPU path, bit-equal to it on the build host)
                timed on this box's host cores on a bounded sample (bs=2, s_step=4, same network).
 """
@@ -326,6 +327,9 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help="launch every kernel from Python instead of replaying the "
                     "HIP graph of the sampling loop (cfg.GaussianDiffusion.hip_graph)")
     ap.add_argument('--no-roofline', action='store_true', help='skip the extra untimed step that carries the HIP events')
+    ap.add_argument('--no-traffic', action='store_true',
+                    help='quote roofline.traffic from the committed PMC profile instead of measuring it (two child runs under '
+                         'rocprofv3 --pmc, ~40 s, after the timed region; single-GPU runs only)')
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the extra steps (after the timed region) that time cfg.Unet.dedup_dropped_rows and report it '
                          'under "variants" (the headline `value` never includes it)')
@@ -491,6 +495,8 @@ def main():
                         'are not computed; the keep mask stays on the device (row subsets of include/dmhomo_hip.h) inside the '
                         'captured step; bitwise identical samples (tests/test_gpu_dedup.py)'}}
         if log:
+            args.measure_traffic = (world == 1 and not args.no_traffic and
+                                    (args.dim, args.image_size, args.bs) == (64, 128, 25))   # (the committed figure's workload)
             res['roofline'] = roofline(log, args)
         if not args.no_cpu_baseline:         # rank 0's host cores, whatever N is (the other ranks wait at the barrier)
             big = args.dim * args.image_size > 64 * 128
@@ -504,9 +510,43 @@ def main():
         dist.destroy_process_group()
 
 
+def measure_traffic(timeout=240):
+    """HBM bytes per stride-1 3x3 launch, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then
+    WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes; --kernel-trace only), on the workload tools/profile_round5.sh
+    uses for the committed figure (one eager batched step at s_step = 2: same launches, same shapes).  Units / corrections as
+    tools/pmc_traffic.py: counters in KiB, FETCH_SIZE doubled on gfx950.  -> (bytes per launch, launches) or raises."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        raise RuntimeError('rocprofv3 not on PATH')
+    kernel = 'conv_f16x3_kernel<3, 3, 1, 0'
+    out = {}
+    env = dict(os.environ, TMPDIR='/tmp')
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = tempfile.mkdtemp(prefix='dmh_pmc_', dir='/tmp')
+        try:
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 't', '--',
+                   sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--s_step', '2', '--cfg-mode',
+                   'batched', '--no-variants', '--no-cpu-baseline', '--no-roofline', '--no-graph']
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd='/tmp', env=env)
+            files = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
+            if r.returncode != 0 or not files:
+                raise RuntimeError(f'rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}')
+            vals = [float(row['Counter_Value']) for row in csv.DictReader(open(files[0]))
+                    if row['Counter_Name'] == counter and kernel in row['Kernel_Name']]
+            if not vals:
+                raise RuntimeError(f'no {counter} rows for {kernel}')
+            out[counter] = (sum(vals) / len(vals), len(vals))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2 * out['FETCH_SIZE'][0] * 1024 + out['WRITE_SIZE'][0] * 1024, out['FETCH_SIZE'][1]
+
+
 def roofline(log, args):
     """the `roofline` object of the JSON line from the HIP-event log of one batched step (see the module docstring)."""
-    fl3 = ms3 = n3 = 0.0            # stride-1 3x3 launches (the dominant kernel): 3 executed fp16 FLOPs per algorithmic one
+    fl3 = ms3 = n3 = by3 = 0.0      # stride-1 3x3 launches (the dominant kernel): 3 executed fp16 FLOPs per algorithmic one
     flc = msc = nc = 0.0            # of those, the canonical 64->64 @ image_size^2 with the GN+SiLU prologue
     flu = msu = 0.0                 # sub-pixel Upsample convs (16 of every 36 taps executed): reported, not in `frac`
     flq = msq = nq = 0.0            # the same shape WITHOUT the prologue (block 1 of a ResnetBlock): reported beside it
@@ -519,6 +559,7 @@ def roofline(log, args):
             flu, msu = flu + fl, msu + ms
             continue
         fl3, ms3, n3 = fl3 + fl, ms3 + ms, n3 + 1
+        by3 += 4.0 * B * ho * wo * (cin + cout) + 4 * (9 * cin * cout + 3 * cout) + 8 * B * cout     # SURVEY 8d, per launch
         if (cin, cout, ho) == (64, 64, args.image_size):
             if pro:
                 flc, msc, nc = flc + fl, msc + ms, nc + 1
@@ -540,6 +581,20 @@ def roofline(log, args):
                 traffic = json.load(f).get('hbm_bytes_per_launch')
             traffic_src = 'profiles/' + name
             break
+    traffic_note = ('HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, averaged over the 3x3 '
+                    'launches of a batched step); from the committed profile, not measured by this run')
+    committed = traffic
+    if getattr(args, 'measure_traffic', False):
+        # measured by THIS run (two child processes under rocprofv3 --pmc, after the timed region); the committed figure stays
+        # beside it, with the deviation — a traffic regression now shows in the driver's own line
+        try:
+            t0 = time.perf_counter()
+            traffic, nl = measure_traffic()
+            traffic_src = 'measured by this run: 2 x rocprofv3 --pmc child passes of bench.py (batched, eager, s_step 2)'
+            traffic_note = (f'HBM bytes per launch: FETCH_SIZE x2 + WRITE_SIZE (separate passes), averaged over {nl} stride-1 3x3 '
+                            f'launches; {time.perf_counter() - t0:.0f} s for the two passes')
+        except Exception as e:                       # (no profiler on the box, a refused counter, a timeout): quote the file
+            traffic_note += f' [live measurement failed: {str(e)[:160]}]'
     return {
         'kernel': 'conv_f16x3_kernel<3,3,1,0,...> (stride-1 3x3 conv, implicit GEMM, 3 x v_mfma_f32_16x16x32_f16 per fp32 '
                   'product block, fp32 accumulate)',
@@ -548,9 +603,15 @@ def roofline(log, args):
         'executed': {'pipe': 'fp16 MFMA', 'TFLOP/s': ach * F16X3_TERMS, 'peak': PEAK_FP16_MFMA_TFLOPS,
                      'frac': ach * F16X3_TERMS / PEAK_FP16_MFMA_TFLOPS},
         'vs_fp32_mfma_peak': ach / PEAK_FP32_MFMA_TFLOPS,
-        'traffic': traffic, 'traffic_source': traffic_src,
-        'traffic_note': 'HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, averaged over the '
-                        '3x3 launches of a batched step); from the committed profile, not measured by this run',
+        'traffic': traffic, 'traffic_source': traffic_src, 'traffic_note': traffic_note,
+        'traffic_committed': committed,
+        'traffic_vs_committed': (traffic / committed) if (traffic and committed) else None,
+        'algorithmic_bytes_per_launch_avg': by3 / max(n3, 1),
+        'traffic_vs_algorithmic_note': 'the canonical launch alone moves 1.02x its algorithmic bytes (profiles/r05_pmc_canonical.json); '
+                                       'the average over ALL stride-1 3x3 launches sits ~1.2x above the SURVEY 8d sum because the <= 32^2 '
+                                       'levels fetch their (small) input once per 128-channel output tile — those tiles run on different '
+                                       'XCDs, i.e. behind different L2s, so that each XCD keeps its weight slice resident (512->512@16^2: 130 MB '
+                                       'fetched for 36 MB of algorithmic reads, at < 1 TB/s: those launches are latency-bound, DESIGN 3.1)',
         'measured_in': 'one extra untimed step, cfg_mode=batched, HIP events on the launch stream',
         'launches': int(n3), 'avg_launch_us': ms3 / max(n3, 1) * 1e3,
         'algorithmic_flop_per_launch': fl3 / max(n3, 1),
