@@ -63,7 +63,8 @@ def test_trunk_row_subset_every_tap_bitwise(dim, size, B):
                 if k == 'init_conv' or v is None:
                     continue
                 assert torch.equal(v[sub], full_taps[k][sub]), (dim, sub, k)
-        if off and dim <= 64:      # (the fused final projection writes the caller's buffer; wider models copy all rows into it)
+        if off and dim <= 64 and ops.f16x3_default():   # (the fused final projection writes the caller's buffer; wider models
+                                                        #  and the exact-fp32 conv variants copy all rows into it)
             assert bool((out[off] == 7.0).all()), (dim, sub)          # the launch never wrote the inactive rows
 
 
@@ -201,3 +202,21 @@ def test_invalid_class_id_poisons_its_row_only(graph):
     for bad in outs[1:]:
         assert torch.isnan(bad[1]).all()
         assert torch.equal(bad[[0, 2]], outs[0][[0, 2]])
+
+
+@pytest.mark.parametrize('variant', ['0', '6'])
+def test_row_subsets_under_exact_fp32_conv_variants_in_child_process(variant):
+    """DMH_CONV3_VARIANT = 0 (exact-fp32 implicit GEMM, conv.hip) / 6 (exact-fp32 Winograd, conv_wino.hip) also take DmhConv.rows:
+    the variant is read once per process, so the subset tests run in a fresh child under it"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMH_CONV3_VARIANT=variant)
+    me = os.path.join(root, 'tests', 'test_gpu_dedup.py')
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-x', '-q', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        me + '::test_trunk_row_subset_every_tap_bitwise', me + '::test_forward_with_cond_scale_dedup_bitwise',
+                        me + '::test_sample_dedup_eager_and_graph_bitwise'],
+                       capture_output=True, text=True, env=env, cwd=root, timeout=1500)
+    print(r.stdout[-3000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
