@@ -86,6 +86,109 @@ def launch_ranks(n, argv):
         sys.exit(rc if rc != 0 else 1)
 
 
+_RDZV_VARS = ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME',
+              'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')
+
+
+def child_env(**extra):
+    """environment of a measurement child (a FRESH process: never a re-exec of this one): the rendezvous variables of a
+    torchrun parent are removed — a one-rank child must not join, or collide with, the parent's still-live process group"""
+    env = {k: v for k, v in os.environ.items() if k not in _RDZV_VARS and not k.startswith('TORCHELASTIC_')}
+    env.update(extra)
+    return env
+
+
+def run_child(cmd, timeout, env=None, cwd=None):
+    """subprocess.run(capture_output=True) for a child that has children of its own (rocprofv3 -> python): the child leads a
+    new session, and on a timeout the whole process GROUP is killed — killing rocprofv3 alone would leave its python child on
+    the GPU holding the pipes, and the read that follows the kill would block for good.  -> (returncode, stdout, stderr);
+    raises subprocess.TimeoutExpired after the group is gone."""
+    import signal
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=cwd,
+                            start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        try:
+            proc.communicate(timeout=15)
+        except subprocess.TimeoutExpired:
+            pass                                             # (a grandchild that left the group still holds a pipe: give up on it)
+        raise
+    return proc.returncode, out, err
+
+
+def smi_sample(device_index):
+    """ONE `rocm-smi --json` call for this rank's GPU (no sampling thread): the SMU's own running averages of clock and
+    socket power, read right before and right after the timed region — on an 8-GPU chassis a throttled GPU (this workload
+    sits on the power limit) shows here.  rocm-smi does not initialise HIP.  -> {field: value} or {'error': ...}"""
+    import re
+    import shutil
+    exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
+    try:
+        r = subprocess.run([exe, '-d', str(device_index), '--showclocks', '--showpower', '--showtemp', '--json'],
+                           capture_output=True, text=True, timeout=20)
+        cards = json.loads(r.stdout.strip().splitlines()[-1])
+        card = next(v for k, v in sorted(cards.items()) if k.startswith('card'))
+        keep = {}
+        for k, v in card.items():
+            if re.search(r'sclk|power|junction', k, re.I):
+                m = re.search(r'-?[0-9]+(\.[0-9]+)?', str(v))
+                keep[k.strip(' :')] = float(m.group(0)) if m else v
+        return keep
+    except Exception as e:                                   # (no rocm-smi, another JSON shape): reported, never fatal
+        return {'error': f'{type(e).__name__}: {str(e)[:120]}'}
+
+
+def conv_error(image_size, dev):
+    """the measured error of THIS process's convolution arithmetic (fp16 pieces by default, the exact-fp32 kernels under
+    DMH_CONV3_VARIANT=6) on the canonical shape: one row of a weight-standardised 3x3 conv 64 -> 64 at image_size^2 on N(0,1)
+    activations (CFG:114-128) against an fp64 F.conv2d on the host; max |y - y64| / max |y64|."""
+    import torch
+    import torch.nn.functional as F
+    from dmhomo_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((1, 64, image_size, image_size), generator=g)
+    w = torch.randn((64, 64, 3, 3), generator=g)
+    b = torch.randn((64,), generator=g)
+    wd = w.double()
+    mean = wd.mean(dim=(1, 2, 3), keepdim=True)
+    var = wd.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    ws = (wd - mean) * (var + 1e-5).rsqrt()
+    ref = F.conv2d(x.double(), ws, b.double(), padding=1)
+    pc = ops.PackedConv(ws.float().contiguous().to(dev), b.to(dev), 64)
+    y = ops.conv2d(pc, x.permute(0, 2, 3, 1).contiguous().to(dev)).permute(0, 3, 1, 2).double().cpu()
+    return float((y - ref).abs().max() / ref.abs().max())
+
+
+def exact_fp32_variant(args, timeout=420):
+    """`variants.exact_fp32`: the same command in a FRESH child process under DMH_CONV3_VARIANT=6 (read once per process:
+    every 3x3 conv on the exact-fp32 Winograd kernel, the other convs on the fp32-MFMA implicit GEMM) — what the precision /
+    throughput trade of `config.arithmetic` buys on THIS box.  -> dict for the JSON line (an 'error' entry when it failed)."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', '3', '--warmup', '1', '--bs', str(args.bs), '--s_step',
+           str(args.s_step), '--image_size', str(args.image_size), '--dim', str(args.dim), '--cfg-mode', args.cfg_mode,
+           '--no-variants', '--no-traffic', '--no-cpu-baseline', '--no-roofline'] + (['--no-graph'] if args.no_graph else [])
+    try:
+        rc, out, err = run_child(cmd, timeout, env=child_env(DMH_CONV3_VARIANT='6'), cwd=ROOT)
+        lines = [l for l in out.splitlines() if l.startswith('{') and '"metric"' in l]
+        if rc != 0 or not lines:
+            return {'error': f'child exit code {rc}: {err[-300:]}'}
+        d = json.loads(lines[-1])
+        return {'value': d['value'], 'unit': 'images/s', 'ms_per_step': d['ms_per_step'],
+                'ms_per_denoise_step': d['ms_per_denoise_step'], 'steps': d['steps'],
+                'measured_rel_error': d['config'].get('measured_rel_error'),
+                'how': 'a fresh child process of this script under DMH_CONV3_VARIANT=6, after the timed region',
+                'arithmetic': 'every conv in exact fp32: 3x3 = Winograd F(2x2,3x3) on fp32 MFMA (conv_wino.hip), the rest = '
+                              'fp32-MFMA implicit GEMM (conv.hip); attention projections unchanged'}
+    except subprocess.TimeoutExpired:
+        return {'error': f'the child did not finish in {timeout} s (its process group was killed)'}
+    except Exception as e:
+        return {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+
+
 def cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -268,6 +371,34 @@ def cpu_baseline(dim, image_size, seconds=12.0, slice_bs=0, conds=None):
     return res
 
 
+def assemble_phases(mine, rank, world, broadcast_ms, broadcast_first_ms):
+    """every rank hands in its own figures (`mine`); rank 0 gets the `phases` object of the JSON line, the others None.
+    How to read it: `value` is global images / the barrier-to-barrier MAXIMUM; a sub-linear N-rank
+    line is then explained by per_rank_ms (one slow rank = `straggler_rank`: look at its smi clocks / power — throttling),
+    by gather_ms (transport of the records to rank 0) or by neither (launch jitter: per_rank_ms_max well under ms_per_step);
+    broadcast_ms is start-up cost outside the timed region."""
+    import torch.distributed as dist
+    every = [mine]
+    if world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+    if rank != 0:
+        return None
+    per = [e['ms_per_step'] for e in every]
+    return {
+        'per_rank_ms': per, 'per_rank_ms_min': min(per), 'per_rank_ms_max': max(per),
+        'per_rank_ms_mean': sum(per) / len(per), 'straggler_rank': per.index(max(per)),
+        'broadcast_ms': broadcast_ms, 'broadcast_first_ms': broadcast_first_ms,
+        'local_ms': [e['local_ms'] for e in every], 'gather_ms': [e['gather_ms'] for e in every],
+        'smi': [{'rank': e['rank'], 'device': e['device'], 'host': e['host'], 'before': e['smi_before'],
+                 'after': e['smi_after']} for e in every],
+        'note': 'per_rank_ms: each rank\'s own wall time per timed step up to ITS last kernel (the line\'s ms_per_step is '
+                'the barrier-to-barrier maximum); broadcast_ms: the weight payload (scatter + all-gather) repeated once '
+                'the communicator exists, broadcast_first_ms: the first call; local_ms / gather_ms: sample + record, '
+                'then — after a barrier — the gather to rank 0, of ONE instrumented step after the timed region; smi: '
+                'one rocm-smi --json call per rank right before / right after the timed loop (the SMU\'s averages)'}
+
+
 def plumbing_only(args):
     """tests/test_distributed_cpu.py only: the N > 1 plumbing of this script (launcher -> ranks -> process group ->
     weight payload -> shards -> gather -> max-over-ranks timing -> ONE JSON line) on gloo / CPU, with the sampling
@@ -284,18 +415,34 @@ def plumbing_only(args):
     torch.manual_seed(rank)                               # different weights per rank before the payload
     model = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1)
     diffusion = cfg.GaussianDiffusion(model, image_size=16, timesteps=50, sampling_timesteps=4, objective='pred_x0')
+    dist.barrier()
+    tb = time.perf_counter()
     D.broadcast_module_(diffusion, src=0)
+    dist.barrier()
+    broadcast_first_ms = (time.perf_counter() - tb) * 1e3
+    tb = time.perf_counter()
+    D.broadcast_module_(diffusion, src=0)
+    dist.barrier()
+    broadcast_ms = (time.perf_counter() - tb) * 1e3
     digest = torch.tensor([float(sum(p.double().sum() for p in diffusion.state_dict().values()))], dtype=torch.float64)
     lo, hi = D.shard_bounds(args.bs * world, rank, world)
     imgs = torch.arange(lo, hi, dtype=torch.uint8).reshape(-1, 1, 1, 1).expand(-1, 6, 4, 4).contiguous()
     homos = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1, 1).expand(-1, 3, 3).contiguous()
+    smi_before = smi_sample(0)
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gi, gh = D.gather_records(imgs, homos, dst=0)
+    elapsed_local = time.perf_counter() - t0
     dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    tg = time.perf_counter()
+    D.gather_records(imgs, homos, dst=0)
+    phases = assemble_phases({'rank': rank, 'ms_per_step': elapsed_local / max(args.steps, 1) * 1e3, 'local_ms': 0.0,
+                              'gather_ms': (time.perf_counter() - tg) * 1e3, 'smi_before': smi_before,
+                              'smi_after': smi_sample(0), 'host': socket.gethostname(), 'device': str(device)},
+                             rank, world, broadcast_ms, broadcast_first_ms)
     ranks = torch.ones(1)
     dist.all_reduce(ranks)
     dmin, dmax = digest.clone(), digest.clone()
@@ -307,7 +454,7 @@ def plumbing_only(args):
         print(json.dumps({'metric': 'plumbing only (no sampling: CPU test mode)', 'value': None, 'n_gpus': world,
                           'steps': args.steps, 'warmup': args.warmup, 'rccl_ranks': int(ranks.item()),
                           'backend': dist.get_backend(), 'plumbing_only': True, 'records_in_rank_order': bool(ok),
-                          'global_batch': args.bs * world, 'elapsed_s': float(t.item())}), flush=True)
+                          'global_batch': args.bs * world, 'elapsed_s': float(t.item()), 'phases': phases}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -333,6 +480,9 @@ def main():
     ap.add_argument('--no-variants', action='store_true',
                     help='skip the extra steps (after the timed region) that time cfg.Unet.dedup_dropped_rows and report it '
                          'under "variants" (the headline `value` never includes it)')
+    ap.add_argument('--no-phases', action='store_true',
+                    help='skip the per-rank / per-phase diagnosis (weight payload, local step, gather, rocm-smi samples: all '
+                         'outside the timed region) reported under "phases"')
     ap.add_argument('--dedup', action='store_true',
                     help='development / profiling: run the TIMED loop itself with cfg.Unet.dedup_dropped_rows (the line is then '
                          'labelled as that variant and is not the headline)')
@@ -376,7 +526,21 @@ def main():
     model.dedup_dropped_rows = bool(args.dedup)
     diffusion = cfg.GaussianDiffusion(model, image_size=args.image_size, timesteps=1000,
                                       sampling_timesteps=args.s_step, loss_type='l1', objective='pred_x0').to(device)
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # the weight payload (scatter + all-gather, distributed.py), timed twice: the first call also builds the communicator
+    fence()
+    tb = time.perf_counter()
     D.broadcast_module_(diffusion, src=0)
+    fence()
+    broadcast_first_ms = (time.perf_counter() - tb) * 1e3
+    tb = time.perf_counter()
+    D.broadcast_module_(diffusion, src=0)
+    fence()
+    broadcast_ms = (time.perf_counter() - tb) * 1e3
     # (ONE denoise step is captured and replayed s_step times: any depth, the 250-step stress configuration included)
     use_graph = not args.no_graph
     diffusion.hip_graph = use_graph
@@ -395,19 +559,38 @@ def main():
         homos = ops.dlt_homography(fl)
         return D.gather_records(imgs_u8, homos, dst=0)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
+    fence()
+    smi_before = smi_sample(device.index or 0) if not args.no_phases else None
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0             # this rank's own finish line (before it waits for the others)
     fence()
     elapsed = time.perf_counter() - t0
+    # ---- phases (N-rank diagnosis; all of it OUTSIDE the timed region): the SMU's averages right after the loop, then one
+    # instrumented step with the local work (sample + record) and the gather timed apart, a barrier between them so that the
+    # gather's time is the transport, not the wait for the slowest rank
+    phases = None
+    if not args.no_phases:
+        smi_after = smi_sample(device.index or 0)
+        fence()
+        tl = time.perf_counter()
+        img_, _, fl_ = diffusion.sample(classes, rgb_flow, flow, mask)
+        u8_, hm_ = ops.to_uint8(img_), ops.dlt_homography(fl_)
+        torch.cuda.synchronize()
+        local_ms = (time.perf_counter() - tl) * 1e3
+        fence()
+        tg = time.perf_counter()
+        D.gather_records(u8_, hm_, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        mine = {'rank': rank, 'ms_per_step': elapsed_local / max(args.steps, 1) * 1e3, 'local_ms': local_ms, 'gather_ms': gather_ms,
+                'smi_before': smi_before, 'smi_after': smi_after, 'host': socket.gethostname(), 'device': str(device)}
+        phases = assemble_phases(mine, rank, world, broadcast_ms, broadcast_first_ms)
     # ---- roofline leg: HIP events on the launch stream around every dmh_conv2d of ONE EXTRA untimed step with the
     # cond + null rows in one launch sequence (exclusive per-launch durations; same kernels, same shapes)
     log = None
@@ -494,6 +677,25 @@ def main():
                         'conditional pass whose class was dropped (p = 0.5, CFG:404,415-425) equal their null-pass rows and '
                         'are not computed; the keep mask stays on the device (row subsets of include/dmhomo_hip.h) inside the '
                         'captured step; bitwise identical samples (tests/test_gpu_dedup.py)'}}
+        if phases is not None:
+            res['phases'] = phases
+        # the measured error of this process's conv arithmetic on the canonical shape (fp64 host reference), and — beside the
+        # headline, from a fresh child process — what the exact-fp32 kernels deliver on this box, with their error
+        own = 'f16x3' if os.environ.get('DMH_CONV3_VARIANT', '9') == '9' else f"DMH_CONV3_VARIANT={os.environ['DMH_CONV3_VARIANT']}"
+        try:
+            res['config']['measured_rel_error'] = {own: conv_error(args.image_size, device)}
+        except Exception as e:
+            res['config']['measured_rel_error'] = {'error': f'{type(e).__name__}: {str(e)[:160]}'}
+        res['config']['measured_rel_error_note'] = ('max |y - y64| / max |y64| of one row of the canonical weight-standardised 3x3 conv '
+                                                    '64->64 at image_size^2 on N(0,1) input against an fp64 host convolution')
+        if not args.no_variants and world == 1 and own == 'f16x3':
+            torch.cuda.synchronize()
+            ex = exact_fp32_variant(args)
+            res['variants']['exact_fp32'] = ex
+            if ex.get('value'):
+                ex['speedup_vs_value'] = ex['value'] / (images / elapsed)
+            if isinstance(ex.get('measured_rel_error'), dict):
+                res['config']['measured_rel_error']['exact_fp32'] = next(iter(ex['measured_rel_error'].values()), None)
         if log:
             args.measure_traffic = (world == 1 and not args.no_traffic and
                                     (args.dim, args.image_size, args.bs) == (64, 128, 25))   # (the committed figure's workload)
@@ -523,17 +725,18 @@ def measure_traffic(timeout=240):
         raise RuntimeError('rocprofv3 not on PATH')
     kernel = 'conv_f16x3_kernel<3, 3, 1, 0'
     out = {}
-    env = dict(os.environ, TMPDIR='/tmp')
+    env = child_env(TMPDIR='/tmp')       # (no RANK / MASTER_*: the child is a one-rank job of its own)
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
         d = tempfile.mkdtemp(prefix='dmh_pmc_', dir='/tmp')
         try:
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 't', '--',
                    sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--s_step', '2', '--cfg-mode',
                    'batched', '--no-variants', '--no-cpu-baseline', '--no-roofline', '--no-graph']
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd='/tmp', env=env)
+            # (rocprofv3 leads its own session: a timeout kills the profiler AND the python under it — run_child)
+            rc, _, err = run_child(cmd, timeout, env=env, cwd='/tmp')
             files = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
-            if r.returncode != 0 or not files:
-                raise RuntimeError(f'rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}')
+            if rc != 0 or not files:
+                raise RuntimeError(f'rocprofv3 --pmc {counter} failed (rc {rc}): {err[-200:]}')
             vals = [float(row['Counter_Value']) for row in csv.DictReader(open(files[0]))
                     if row['Counter_Name'] == counter and kernel in row['Kernel_Name']]
             if not vals:

@@ -7,7 +7,7 @@ so scripts written against the reference (``DGM/dgm_sample.py:28-38``) run
 unchanged — but every tensor value is produced by the gfx950 kernels of
 libdmhomo_hip.so (see ``engine.py``).  There is no CPU path.
 """
-from collections import namedtuple
+from collections import OrderedDict, namedtuple
 
 import torch
 from torch import nn
@@ -505,7 +505,12 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
     # img = x_start, CFG:693-695) is a second graph in the same memory pool.  Same kernels, same order, same device RNG
     # stream (the Philox offsets are graph inputs): results are bitwise those of the eager path, the capturing call
     # included (the RNG state is restored after the eager warm-up).  Off by default; bench.py switches it on.
+    # Captured steps are kept in a small least-recently-used cache (``graph_cache_size`` entries, each with its own graphs,
+    # memory pool and static buffers): a job that alternates batch shapes — the short last batch of every epoch of
+    # scripts/dgm_sample.py's loader, two samplers sharing one model — captures each shape once, not once per alternation.
     hip_graph = False
+    graph_cache_size = 4
+    graph_captures = 0                   # captures made by this object so far (tests count them)
 
     @torch.no_grad()
     def sample(self, classes, rgb_flow, flow, mask, cond_scale=3.):
@@ -530,8 +535,11 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                bool(self.model.dedup_dropped_rows), bool(self.model.share_first_conv), float(self.model.cond_drop_prob), eng._sig, self.sampling_timesteps,
                self.num_timesteps, self.objective, float(self.ddim_sampling_eta), clip, self.__dict__['_host_cache'][0],
                str(device), self.rng.graph_key())
-        st = self.__dict__.get('_graph_state')
-        if st is None or st['key'] != key:
+        cache = self.__dict__.setdefault('_graph_states', OrderedDict())
+        st = cache.get(key)
+        if st is not None:
+            cache.move_to_end(key)
+        else:
             steps, times = [], []
             for time, time_next in ddim_pairs(self.num_timesteps, self.sampling_timesteps):
                 if time_next < 0:
@@ -587,7 +595,11 @@ class GaussianDiffusion(nn.Module, ScheduleHost):
                 self.model.__dict__.pop('_ss_tab', None)
             self.rng.restore(rng_state, device)
             st['graph'], st['graph_last'] = g_mid, g_last
-            self.__dict__['_graph_state'] = st
+            cache[key] = st
+            self.graph_captures = self.graph_captures + 1
+            while len(cache) > max(int(self.graph_cache_size), 1):
+                cache.popitem(last=False)                    # least recently used: its graphs, pool and buffers go with it
+        self.__dict__['_graph_state'] = st                   # (the entry this call replays)
         for dst, src in zip(st['ins'], (classes, rgb_flow, mask)):
             dst.copy_(src)
         ops.affine(st['ins'][1], 2., -1., out=st['rf'])      # normalize_to_neg_one_to_one, CFG:716

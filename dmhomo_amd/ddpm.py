@@ -385,13 +385,13 @@ def _clone_without_engine_caches(model):
             engines.append(eng)
         # training kernels' state (packed weights, a HIP graph), the captured sampling-step graphs with their static
         # buffers and the host mirrors of the schedule: caches of THIS module, not state — not copied
-        for name in ('_dmh_train_step', '_graph_state', '_host_cache'):
+        for name in ('_dmh_train_step', '_graph_state', '_graph_states', '_host_cache'):
             ts = mod.__dict__.get(name)
             if ts is not None:
                 memo[id(ts)] = None
     new = copy.deepcopy(model, memo)
     for mod in new.modules():
-        for name in ('_dmh_train_step', '_graph_state', '_host_cache'):
+        for name in ('_dmh_train_step', '_graph_state', '_graph_states', '_host_cache'):
             mod.__dict__.pop(name, None)
     it = iter(engines)
     for mod in new.modules():

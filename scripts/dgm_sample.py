@@ -92,6 +92,9 @@ def main():
                     np.array(train_list, dtype=object), allow_pickle=True)
             train_list.clear()
             part += 1
+    # (captured denoise steps live in an LRU keyed by batch shape: a loader whose epochs end on a short batch captures twice per
+    #  job, not twice per epoch)
+    print(f'rank {rank}: graph captures {sampler.graph_captures}')
 
 
 if __name__ == '__main__':

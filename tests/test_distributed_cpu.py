@@ -219,6 +219,12 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert res['n_gpus'] == 8 and res['rccl_ranks'] == 8 and res['records_in_rank_order'] and res['global_batch'] == 24
+    # the per-rank / per-phase diagnosis an N-rank line carries (bench.assemble_phases): one entry per rank, in rank order
+    ph = res['phases']
+    assert len(ph['per_rank_ms']) == 8 == len(ph['gather_ms']) == len(ph['local_ms']) == len(ph['smi'])
+    assert ph['per_rank_ms_min'] <= ph['per_rank_ms_mean'] <= ph['per_rank_ms_max'] and 0 <= ph['straggler_rank'] < 8
+    assert ph['per_rank_ms'][ph['straggler_rank']] == ph['per_rank_ms_max'] and ph['broadcast_ms'] > 0 and ph['broadcast_first_ms'] > 0
+    assert [e['rank'] for e in ph['smi']] == list(range(8)) and all('before' in e and 'after' in e for e in ph['smi'])
     # outside the test the CPU mode refuses to run, and a failing child makes the launcher exit non-zero
     env.pop('DMH_BENCH_PLUMBING_TEST')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--device', 'cpu'],

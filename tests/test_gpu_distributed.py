@@ -138,6 +138,31 @@ def test_ranks_shard_a_job_and_reproduce_the_single_process_records(tmp_path, ra
     assert r.returncode == 0 and 'RANKS-OK' in r.stdout
 
 
+def test_dgm_sample_short_last_batch_captures_once_per_shape(tmp_path):
+    """scripts/dgm_sample.py over a condition set whose size is not a multiple of --bs (two epochs of 8 items at bs 3: batches
+    of 3, 3, 2, 3, 3, 2 — the reference's DataLoader keeps the short last batch, DDP:1746-1752): the captured denoise steps
+    are kept per batch shape (cfg.GaussianDiffusion.graph_cache_size), so the job captures twice, not twice per epoch."""
+    import numpy as np
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    S = 32
+    gen = torch.Generator().manual_seed(3)
+    batches = [(torch.rand((n, 12, S, S), generator=gen), torch.zeros(n, dtype=torch.long)) for n in (3, 3, 2, 3, 3, 2)]
+    torch.save(batches, str(tmp_path / 'cond.pt'))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'dgm_sample.py'), '-c', 'absent', '--s_step', '3', '--bs', '3',
+                        '--exp', 'run0', '--image_size', str(S), '--seed', '5', '--batches', '6', '--conditions',
+                        str(tmp_path / 'cond.pt')], capture_output=True, text=True, env=env, cwd=str(tmp_path), timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'rank 0: graph captures 2' in r.stdout, r.stdout[-1500:]
+    recs = []
+    for part in range(3):
+        recs.extend(np.load(str(tmp_path / 'traindata' / 'run0' / 'dataset' / f'idx_0_rank_0_part_{part}_dm_cahomo_0.006k.npy'),
+                            allow_pickle=True))
+    assert [r_['imgs'].shape[0] for r_ in recs] == [3, 3, 2, 3, 3, 2]
+
+
 @pytest.mark.parametrize('ranks', [1, 2, 8])
 def test_dgm_sample_script_end_to_end(tmp_path, ranks):
     """scripts/dgm_sample.py (the counterpart of DGM/dgm_sample.py: same flags, same record files) as a user starts it —
@@ -223,6 +248,40 @@ def test_bench_ranks_on_one_gpu(ranks, extra):
     assert d['n_gpus'] == ranks and d['rccl_ranks'] == ranks and d['backend'] == 'gloo' and d['scaling'] == 'weak'
     assert d['config']['global_batch'] == int(extra[1]) * ranks and d['value'] > 0 and d['steps'] == 2
     assert d['variants']['dedup_dropped_rows']['value'] > 0
+    # the per-rank / per-phase diagnosis: one entry per rank, the weight payload, local step and gather
+    # timed apart (outside the timed region), one rocm-smi sample per rank before / after the timed loop
+    ph = d['phases']
+    assert len(ph['per_rank_ms']) == ranks == len(ph['gather_ms']) == len(ph['local_ms']) == len(ph['smi'])
+    assert ph['per_rank_ms_min'] <= ph['per_rank_ms_mean'] <= ph['per_rank_ms_max'] <= d['ms_per_step'] * 1.001
+    assert 0 <= ph['straggler_rank'] < ranks and ph['broadcast_ms'] > 0 and min(ph['local_ms']) > 0
+    assert all(isinstance(e['after'], dict) for e in ph['smi'])
+    print('[phases]', json.dumps(ph)[:1500])
+    assert 'exact_fp32' not in d['variants']               # (N = 1 only: a child process of a one-rank run)
+    assert d['config']['measured_rel_error']['f16x3'] < 2e-6
+
+
+def test_bench_single_gpu_line_carries_exact_fp32_and_measured_error():
+    """the N = 1 line (a small model): `variants.exact_fp32` from a fresh child process under DMH_CONV3_VARIANT=6 (value,
+    ms_per_step, slower than or equal to the fp16-piece headline is NOT asserted on a toy model), `config.measured_rel_error`
+    with the measured error of both arithmetics on the canonical conv shape against fp64 (both fp32-class), and `phases`."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.pop('DMH_CONV3_VARIANT', None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--s_step', '4', '--steps', '2', '--warmup', '1', '--bs', '3',
+                        '--dim', '8', '--image_size', '32', '--no-cpu-baseline', '--no-roofline'], capture_output=True, text=True,
+                       env=env, cwd=root, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    ex = d['variants']['exact_fp32']
+    assert 'error' not in ex, ex
+    assert ex['value'] > 0 and ex['ms_per_step'] > 0 and ex['steps'] == 3 and ex['speedup_vs_value'] > 0
+    err = d['config']['measured_rel_error']
+    print('[parity] canonical conv, measured rel. error vs fp64:', err)
+    assert 0 < err['f16x3'] < 2e-6 and 0 < err['exact_fp32'] < 2e-6
+    ph = d['phases']
+    assert len(ph['per_rank_ms']) == 1 and ph['per_rank_ms'][0] <= d['ms_per_step'] * 1.001 and ph['local_ms'][0] > 0
+    assert isinstance(ph['smi'][0]['after'], dict)
 
 
 def test_train_bench_eight_ranks_on_one_gpu():

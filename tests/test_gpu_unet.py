@@ -319,6 +319,72 @@ def test_sample_fullsize_vs_oracle_and_properties():
     assert float(img.min()) >= 0 and float(img.max()) <= 1
 
 
+def test_sample_config0_as_written():
+    """BASELINE configs[0] literally: dim=64, 128x128, bs=2, s_step=4 at the reference's timesteps=1000 (CFG:669-711).  The
+    first DDIM jump (999 -> 749) has alpha ~ 2.4e-9, so the reference's radicand 1 - alpha' - sigma^2 (CFG:701) is fp32
+    cancellation noise: 0 or -6e-8 (-> c = NaN and an all-NaN image) depending on how the host's libm rounds; the product
+    clamps it at 0 (cfg.py _ddim_coef, the documented deviation).  Checked here: the oracle's own radicand on THIS host is
+    printed; the product is finite, in [0, 1], graph == eager bitwise, draw count as the reference's; and wherever the
+    oracle is finite (everywhere or nowhere) the image agrees with it within the sampler gate and +-1 uint8 LSB.  If the
+    oracle is NaN on this host the comparison runs against the oracle with the same clamp (the only difference)."""
+    from dmhomo_amd import cfg
+    from dmhomo_amd import ops
+    m, sd = make_cfg(64)
+    d = cfg.GaussianDiffusion(m, image_size=128, timesteps=1000, sampling_timesteps=4, objective='pred_x0').to(dev())
+    B = 2
+    _, rf, mk = _cond_inputs(B, 128, 410)
+    rf01, flow, c = (rf + 1) / 2, rand((B, 2, 128, 128), 413), torch.zeros(B, dtype=torch.long)
+    buf = OD.schedule_buffers(1000, 'cosine')
+    ac = buf['alphas_cumprod']
+    a, an = ac[999], ac[749]
+    sigma = ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+    radicand = float(1 - an - sigma ** 2)
+    print(f'[parity] configs[0]: the oracle\'s first-jump radicand on this host = {radicand!r} '
+          f'(alpha = {float(a):.3e}, alpha_next = {float(an):.6f}, sigma = {float(sigma):.6f})')
+    torch.manual_seed(99)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rec = OD.RecordRng()
+    with torch.no_grad():
+        ref, _, _ = OD.cfg_sample(sd, buf, c, rf01, flow, mk, image_size=128, channels=6, sampling_timesteps=4,
+                                  objective='pred_x0', rng=rec)
+    assert len(rec.draws) == 1 + 4 + 3                      # initial noise, 4 class-dropout draws, 3 step noises
+    finite = torch.isfinite(ref)
+    assert bool(finite.all()) or not bool(finite.any())     # NaN in c poisons every element of the first update
+    if not bool(finite.all()):
+        assert radicand < 0
+        orig = OD._ddim_update
+
+        def clamped(buf_, x_start, pred_noise, time, time_next, eta, noise):   # the reference's update with the radicand at 0
+            alpha, alpha_next = buf_['alphas_cumprod'][time], buf_['alphas_cumprod'][time_next]
+            sg = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+            cc = (1 - alpha_next - sg ** 2).clamp(min=0).sqrt()
+            return x_start * alpha_next.sqrt() + cc * pred_noise + sg * noise
+        OD._ddim_update = clamped
+        try:
+            with torch.no_grad():
+                ref, _, _ = OD.cfg_sample(sd, buf, c, rf01, flow, mk, image_size=128, channels=6, sampling_timesteps=4,
+                                          objective='pred_x0', rng=OD.ReplayRng(rec.draws))
+        finally:
+            OD._ddim_update = orig
+        print('[parity] configs[0]: the oracle is NaN on this host; compared with the oracle under the radicand clamp')
+    d.rng = ReplayDeviceRng(rec.draws)
+    img, mk2, fl2 = d.sample(g(c), g(rf01), g(flow), g(mk))
+    assert d.rng.i == len(rec.draws)
+    assert bool(torch.isfinite(img).all()) and float(img.min()) >= 0 and float(img.max()) <= 1
+    assert torch.equal(mk2.cpu(), mk) and torch.equal(fl2.cpu(), flow)
+    close('configs[0] sample (T=1000, S=4)', img.cpu(), ref, rtol=0, atol=4e-4)
+    u8 = ops.to_uint8(img).cpu().numpy().astype(np.int32)
+    ru8 = (ref.numpy() * 255).astype(np.uint8).astype(np.int32)
+    assert np.abs(u8 - ru8).max() <= 1
+    # the captured step against the eager loop, on the device generator (bitwise)
+    d.rng = cfg.DeviceRng().key_by_sample(7, range(B), dev())
+    eager = d.sample(g(c), g(rf01), g(flow), g(mk))[0]
+    d.hip_graph = True
+    d.rng.key_by_sample(7, range(B), dev())
+    assert torch.equal(d.sample(g(c), g(rf01), g(flow), g(mk))[0], eager)
+    d.hip_graph = False
+
+
 @pytest.mark.parametrize('S', [16, 32])
 def test_ddim_trace_s32_vs_golden(golden_dir, S):
     """F5 at the README's s_step = 32, T = 1000 (tests/golden/make_golden_r2.py): the reference's own 32-step sample()
@@ -520,6 +586,39 @@ def test_sample_hip_graph_equals_eager(mode, S, size):
     g_old = d.__dict__['_graph_state']['graph']
     assert torch.equal(run(True, 5, rf01), e)
     assert d.__dict__['_graph_state']['graph'] is not g_old
+    d.hip_graph = False
+
+
+def test_graph_cache_keeps_alternating_batch_shapes():
+    """The captured steps live in a small LRU (GaussianDiffusion.graph_cache_size = 4): a job that alternates a full and a
+    short batch — the last batch of every epoch of scripts/dgm_sample.py's loader (DDP:1746-1752 keeps it) — captures each
+    shape ONCE (bs 5 / bs 3 / bs 5 / bs 3: two captures, the second round replays), every call bitwise the eager call, with
+    the keyed generator a short batch reads through a view (cfg.DeviceRng.ids_for); the cache evicts least-recently-used."""
+    from dmhomo_amd import cfg
+    m, sd = make_cfg(8)
+    m.cfg_mode, m.dedup_dropped_rows = 'streams', True
+    size = 16
+    d = cfg.GaussianDiffusion(m, image_size=size, timesteps=1000, sampling_timesteps=5, objective='pred_x0').to(dev())
+    _, rf, mk = _cond_inputs(5, size, 910)
+    rf01, flow, c, mk = g((rf + 1) / 2), g(rand((5, 2, size, size), 913)), g(torch.zeros(5, dtype=torch.long)), g(mk)
+
+    def run(graph, n, seed):
+        d.hip_graph = graph
+        d.rng.key_by_sample(seed, range(100, 105), dev())
+        return d.sample(c[:n], rf01[:n], flow[:n], mk[:n])[0]
+    d.rng = cfg.DeviceRng()
+    eager = {(n, s): run(False, n, s) for n in (5, 3, 2) for s in (1, 2)}
+    assert d.graph_captures == 0
+    for rnd, s in ((0, 1), (1, 2)):
+        for n in (5, 3):
+            assert torch.equal(run(True, n, s), eager[(n, s)]), (rnd, n)
+        assert d.graph_captures == 2, d.graph_captures          # the second round replays both
+    st5 = d.__dict__['_graph_states']
+    assert len(st5) == 2
+    d.graph_cache_size = 2                                      # a third shape evicts the least recently used (bs 5)
+    assert torch.equal(run(True, 2, 1), eager[(2, 1)]) and d.graph_captures == 3 and len(st5) == 2
+    assert torch.equal(run(True, 3, 1), eager[(3, 1)]) and d.graph_captures == 3      # bs 3 survived
+    assert torch.equal(run(True, 5, 2), eager[(5, 2)]) and d.graph_captures == 4      # bs 5 did not
     d.hip_graph = False
 
 

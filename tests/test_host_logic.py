@@ -225,3 +225,45 @@ def test_bench_roofline_is_a_fraction_of_the_pipe_that_runs():
     assert abs(r['hbm_frac_canonical'] - 419604224.0 / 190e-6 / 8e12) < 1e-9
     assert r['canonical_64to64_128sq']['launches'] == 2 and r['subpixel_upsample_convs']['TFLOP/s_algorithmic'] > 0
     assert r['traffic'] is None or r['traffic_source'].startswith('profiles/')
+
+
+def test_bench_measurement_children_are_fresh_bounded_and_outside_the_rendezvous():
+    """bench.py's measurement children (the rocprofv3 --pmc traffic passes, the exact-fp32 variant): their environment carries
+    none of a torchrun parent's rendezvous variables (a one-rank child must not join the parent's live process group), and a
+    child that hangs WITH a grandchild holding its pipes — rocprofv3 -> python is that shape — is killed as a process group:
+    run_child raises TimeoutExpired promptly instead of blocking in the read after the kill."""
+    import importlib.util
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bench_mod2', os.path.join(root, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    saved = dict(os.environ)
+    try:
+        os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29511',
+                          TORCHELASTIC_RUN_ID='x', GROUP_RANK='0')
+        env = bench.child_env(DMH_CONV3_VARIANT='6')
+    finally:
+        os.environ.clear()
+        os.environ.update(saved)
+    assert env['DMH_CONV3_VARIANT'] == '6'
+    assert not any(k in env for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'GROUP_RANK'))
+    assert not any(k.startswith('TORCHELASTIC_') for k in env)
+    rc, out, err = bench.run_child([sys.executable, '-c', 'print("ok")'], 30)
+    assert rc == 0 and out.strip() == 'ok'
+    # parent sleeps, its child (same session, inherits the pipes) sleeps longer: both must be gone after the timeout
+    code = ('import subprocess, sys, time\n'
+            'p = subprocess.Popen([sys.executable, "-c", "import time; print(\\"grandchild\\", flush=True); time.sleep(600)"])\n'
+            'print(p.pid, flush=True)\n'
+            'time.sleep(600)\n')
+    t0 = time.time()
+    try:
+        bench.run_child([sys.executable, '-c', code], 3)
+        raise AssertionError('no timeout')
+    except subprocess.TimeoutExpired:
+        pass
+    assert time.time() - t0 < 30
+    # smi_sample never raises (no rocm-smi / no GPU here: an 'error' entry)
+    assert isinstance(bench.smi_sample(0), dict)
