@@ -714,7 +714,7 @@ def main():
 
 def measure_traffic(timeout=240):
     """HBM bytes per stride-1 3x3 launch, measured NOW: two child runs of this script under `rocprofv3 --pmc` (FETCH_SIZE, then
-    WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes; --kernel-trace only), on the workload tools/profile_round5.sh
+    WRITE_SIZE: separate passes, as MI355X_MICROARCH.md prescribes; --kernel-trace only), on the workload tools/profile_round6.sh
     uses for the committed figure (one eager batched step at s_step = 2: same launches, same shapes).  Units / corrections as
     tools/pmc_traffic.py: counters in KiB, FETCH_SIZE doubled on gfx950.  -> (bytes per launch, launches) or raises."""
     import csv
@@ -747,6 +747,13 @@ def measure_traffic(timeout=240):
     return 2 * out['FETCH_SIZE'][0] * 1024 + out['WRITE_SIZE'][0] * 1024, out['FETCH_SIZE'][1]
 
 
+def newest_committed_traffic():
+    """profiles/rNN_pmc_traffic.json with the highest NN (what tools/check_traffic.py resolves for a directory argument)"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic.json')))
+    return files[-1] if files else None
+
+
 def roofline(log, args):
     """the `roofline` object of the JSON line from the HIP-event log of one batched step (see the module docstring)."""
     fl3 = ms3 = n3 = by3 = 0.0      # stride-1 3x3 launches (the dominant kernel): 3 executed fp16 FLOPs per algorithmic one
@@ -777,13 +784,11 @@ def roofline(log, args):
     canon_bytes = 4.0 * rows * args.image_size ** 2 * (64 + 64) + 4 * (9 * 64 * 64 + 3 * 64) + 8 * rows * 64
     canon_us = msc / max(nc, 1) * 1e3
     traffic, traffic_src = None, None
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-        tpath = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(tpath):       # FETCH_SIZE / WRITE_SIZE passes of rocprofv3 (tools/profile_round.sh)
-            with open(tpath) as f:
-                traffic = json.load(f).get('hbm_bytes_per_launch')
-            traffic_src = 'profiles/' + name
-            break
+    tpath = newest_committed_traffic()
+    if tpath:                           # FETCH_SIZE / WRITE_SIZE passes of rocprofv3 (tools/profile_round6.sh)
+        with open(tpath) as f:
+            traffic = json.load(f).get('hbm_bytes_per_launch')
+        traffic_src = 'profiles/' + os.path.basename(tpath)
     traffic_note = ('HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes, averaged over the 3x3 '
                     'launches of a batched step); from the committed profile, not measured by this run')
     committed = traffic

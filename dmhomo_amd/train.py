@@ -192,6 +192,12 @@ class UnetTrain:
         """build everything from the module's parameters (first use, or after their storage moved)"""
         sd = {k: v.detach().to(torch.float32).contiguous() for k, v in self.module.named_parameters()}
         self.sd = sd
+        if 'time_mlp.0.weights' in sd or any(k.startswith('time_mlp.0.') for k, _ in self.module.named_buffers()):
+            # RandomOrLearnedSinusoidalPosEmb (CFG:175-190): its embedding is learned_dim + 1 wide and time_mlp.1 is sized for
+            # THAT — the sinusoidal embedding below would feed it a wrong K silently.  No training entry point reaches such a
+            # model (GaussianDiffusion refuses it, CFG:514-515); anything else that does gets told.
+            raise NotImplementedError('training a Unet with learned_sinusoidal_cond / random_fourier_features is not supported: '
+                                      'the training step has no gradient for RandomOrLearnedSinusoidalPosEmb.weights')
         self.pack = pb = ops.PackBatch()
         self.dim = sd['time_mlp.1.weight'].shape[1]
         half = self.dim // 2

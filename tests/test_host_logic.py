@@ -267,3 +267,15 @@ def test_bench_measurement_children_are_fresh_bounded_and_outside_the_rendezvous
     assert time.time() - t0 < 30
     # smi_sample never raises (no rocm-smi / no GPU here: an 'error' entry)
     assert isinstance(bench.smi_sample(0), dict)
+
+
+def test_training_refuses_learned_sinusoidal_models():
+    """train.UnetTrain derives its sinusoidal embedding width from time_mlp.1 — sized for learned_dim + 1 inputs on a Unet built
+    with learned_sinusoidal_cond / random_fourier_features (CFG:175-190, 336-344): a silent K mismatch, unreachable through
+    GaussianDiffusion (which refuses such a model, CFG:514-515) and refused loudly for anyone who gets there another way."""
+    import pytest
+    from dmhomo_amd import cfg, train
+    for kw in (dict(learned_sinusoidal_cond=True), dict(random_fourier_features=True)):
+        m = cfg.Unet(dim=8, dim_mults=(1, 2), channels=6, num_classes=1, **kw)
+        with pytest.raises(NotImplementedError, match='learned_sinusoidal_cond'):
+            train.UnetTrain(m)

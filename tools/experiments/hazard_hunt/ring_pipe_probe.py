@@ -14,12 +14,12 @@ pla = ops.PackedLinAttn(rand((384, C, 1, 1), 52, C ** -0.5).to(dev))
 x = (rand((B, H, H, C), 50) * 1.3 + 0.2).to(dev)
 n = H * H
 stats = torch.empty((B, n, 2), device=dev)
-call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, C, 1e-5)
+call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, C, 1e-5, None, 0)
 ns = lib().dmh_linattn_fused_splits(B, n)
 def kv(xx, ss):
     b = xx.shape[0]
     part = torch.zeros((b, ns, 4, 1088), device=dev)
-    call('dmh_linattn_fused_context', ptr(xx), ptr(ss), ptr(g), ptr(pla.wpack), ptr(part), b, n, C)
+    call('dmh_linattn_fused_context', ptr(xx), ptr(ss), ptr(g), ptr(pla.wpack), ptr(part), b, n, C, None)
     return part
 alone = kv(x[:2].contiguous(), stats[:2].contiguous())
 w = rand((128, 128, 3, 3), 90, (1.0 / 1152) ** 0.5).to(dev)

@@ -27,9 +27,9 @@ for (B, n) in ((25, 16384), (25, 4096), (25, 1024)):
     partial = torch.randn(B, ns, 4, 1088, device=dev).abs()
     ctx = torch.empty(B, 4, 32, 32, device=dev)
     for _ in range(5):
-        call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
+        call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns, None)
     torch.cuda.synchronize(); e0.record()
     for _ in range(200):
-        call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns)
+        call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns, None)
     e1.record(); torch.cuda.synchronize()
     print('linattn_merge B=%d n=%d (%d splits): %.1f us per launch' % (B, n, ns, e0.elapsed_time(e1) * 1e3 / 200))

@@ -1,8 +1,8 @@
-# rocprofv3 passes behind profiles/r05_* (round 5).  gpurun -- bash tools/profile_round5.sh ; outputs under gpurun_out/r5/,
+# rocprofv3 passes behind profiles/r06_* (round 6).  gpurun -- bash tools/profile_round6.sh ; outputs under gpurun_out/r6/,
 # copied into profiles/ by hand.  Every counter pass is its own run with --kernel-trace only (no other trace domain).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r5
+O=$R/gpurun_out/r6
 rm -rf $O && mkdir -p $O
 stats() { find $1 -name '*kernel_stats.csv' | head -1; }
 # 1. headline line, streams / batched kernel traces, PMC traffic of the 3x3 launches
@@ -14,8 +14,8 @@ cp "$(stats $O/batched)" $O/bench_batched_kernel_stats.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --s_step 2 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline --no-graph > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --s_step 2 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline --no-graph > $O/pmc_write.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 'conv_f16x3_kernel<3, 3, 1, 0' $O/pmc_traffic.json > /dev/null
-# (bench.py quotes roofline.traffic from the COMMITTED profile: a fresh pass that disagrees with it by > 3 % fails here)
-python3 $R/tools/check_traffic.py $O/pmc_traffic.json $R/profiles/r04_pmc_traffic.json > $O/traffic_check.txt 2>&1; echo "traffic check exit $?" >> $O/traffic_check.txt
+# (the same comparison bench.py prints as roofline.traffic_vs_committed: a fresh pass against the NEWEST committed figure)
+python3 $R/tools/check_traffic.py $O/pmc_traffic.json $R/profiles > $O/traffic_check.txt 2>&1; echo "traffic check exit $?" >> $O/traffic_check.txt
 # 1b. the de-duplicating step (cfg.Unet.dedup_dropped_rows) as the timed loop: kernel trace
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/dedup -o s -- python3 $R/bench.py --steps 2 --warmup 1 --dedup --no-variants --no-cpu-baseline --no-roofline > $O/dedup.log 2>&1
 cp "$(stats $O/dedup)" $O/bench_dedup_streams_kernel_stats.csv

@@ -96,12 +96,15 @@ def run(a):
     line.update({'steps': a.steps, 'warmup': a.warmup, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                  'dtype': 'f32', 'data': 'synthetic'})
     if world > 1:
-        # every rank applied the same averaged gradient with the same Adam state: the parameters must agree bit for bit
-        dig = torch.stack([p.detach().double().sum() for p in ts.params.values()]).sum().reshape(1)
-        lo, hi = dig.clone(), dig.clone()
-        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
-        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
-        line['ranks_agree'] = bool(float(lo) == float(hi))
+        # every rank applied the same averaged gradient with the same Adam state: the parameters must agree BIT FOR BIT —
+        # compared as bit patterns (rank 0's int32 view travels to every rank; a sum of sums could cancel, and NaNs compare
+        # unequal to themselves), the verdict reduced with MIN over the ranks
+        flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in ts.params.values()]).contiguous().view(torch.int32)
+        ref = flat.clone()
+        torch.distributed.broadcast(ref, src=0)
+        same = torch.tensor([int(torch.equal(ref, flat))], device=flat.device, dtype=torch.int32)
+        torch.distributed.all_reduce(same, op=torch.distributed.ReduceOp.MIN)
+        line['ranks_agree'] = bool(int(same.item()) == 1)
         line['backend'] = torch.distributed.get_backend()
     if a.torch and rank == 0:
         line['torch_autograd_same_gpu'] = torch_leg(a, dev)
