@@ -272,9 +272,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-extern "C" int dmh_linattn_splits(int n) { return cdiv(n, LA_NS); }
+extern "C" int dmh_linattn_splits(int n) { return dmh_dims_ok({n}, 1, 1 << 26) ? cdiv(n, LA_NS) : -1; }
 
 extern "C" int64_t dmh_linattn_partial_floats(int B, int n) {
+  if (!dmh_dims_ok({B}) || !dmh_dims_ok({n}, 1, 1 << 26)) return -1;
   return (int64_t)B * dmh_linattn_splits(n) * 4 * LA_PART;
 }
 

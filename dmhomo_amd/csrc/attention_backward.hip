@@ -251,6 +251,7 @@ __global__ void sum_slabs_kernel(const float* __restrict__ in, float* __restrict
 
 // ------------------------------------------------------------------------------------------ C ABI
 extern "C" int64_t dmh_linattn_bwd_workspace_floats(int B, int n) {
+  if (!dmh_dims_ok({B}) || !dmh_dims_ok({n}, 1, 1 << 26)) return -1;
   const int ns = cdiv(n, LAB_NS), nc = cdiv(n, 256);
   return (int64_t)B * n * 128                 // qs
          + (int64_t)ns * B * 4 * 1024         // dctx partials

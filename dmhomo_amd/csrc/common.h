@@ -1,5 +1,6 @@
 // Shared helpers for the gfx950 kernels of libdmhomo_hip.so.
 #pragma once
+#include <initializer_list>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -24,6 +25,15 @@ void dmh_set_error(const char* fmt, ...);
       return DMH_ELAUNCH;                                             \
     }                                                                 \
   } while (0)
+
+// size arguments of the pure host entry points (dmh_*_floats, dmh_conv_tiles, ...): a dimension outside (0, 2^20] — a caller's
+// uninitialised or overflowed int — is answered with -1 instead of entering the size arithmetic (found by the host-side
+// sanitizer build, make asan: a 2^30 channel count overflowed the int64 product)
+static inline bool dmh_dims_ok(std::initializer_list<long long> dims, long long lo = 1, long long hi = 1 << 20) {
+  for (long long d : dims)
+    if (d < lo || d > hi) return false;
+  return true;
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

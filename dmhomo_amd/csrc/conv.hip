@@ -351,10 +351,12 @@ static int conv_kc_v(int KH, int stride) {
 }
 
 extern "C" int dmh_conv_tiles(int Hout, int Wout, int KH, int stride) {
+  if (!dmh_dims_ok({Hout, Wout})) return -1;
   return cdiv(Hout, conv_th(KH, stride)) * cdiv(Wout, 16);
 }
 
 extern "C" int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW) {
+  if (!dmh_dims_ok({Cout, C0}) || !dmh_dims_ok({C1}, 0) || !dmh_dims_ok({KH, KW}, 1, 16)) return -1;
   if (KH == 3 && conv3_variant() == 6) return dmh_wino_pack_floats(Cout, C0, C1);
   if (use_f16x3(KH, (KH == 4 || KH == 2) ? 2 : 1) || use_f16x3_s2d(KH, 2, C0, C1))
     return dmh_f16x3_pack_floats(Cout, C0, C1, KH, KW);
@@ -384,6 +386,7 @@ extern "C" int dmh_pack_conv_weight(const float* w, float* wpack, int Cout, int 
 // Upsample(nearest x2) + conv3x3 in its sub-pixel form (DmhConv.upsample2 == 2): -1 floats when this build / variant does
 // not offer it (the caller then packs with dmh_pack_conv_weight and upsample2 = 1)
 extern "C" int64_t dmh_conv_up2_pack_floats(int Cout, int C0) {
+  if (!dmh_dims_ok({Cout, C0})) return -1;
   if (!use_f16x3(3, 1) || Cout % 64 != 0 || C0 % 4 != 0) return -1;
   return dmh_f16x3_up2_pack_floats(Cout, C0);
 }

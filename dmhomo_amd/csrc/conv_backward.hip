@@ -607,6 +607,8 @@ static int wgrad_cw(int KH) { return KH == 7 ? 16 : 64; }  // input channels per
 // stored input (ups = 1: the stored input is H/2 x W/2).  KH = 2: 'valid' 2x2 conv whose stored input is (H+1) x (W+1)
 // (the space-to-depth view of the Downsample conv).
 extern "C" int64_t dmh_conv_wgrad_workspace_floats(int B, int H, int W, int C0, int C1, int Cout, int KH) {
+  if (!dmh_dims_ok({B, H, W, C0, Cout}) || !dmh_dims_ok({C1}, 0) || !dmh_dims_ok({KH}, 1, 16) ||
+      (long long)B * H * W > (1ll << 31)) return -1;
   const int npairs = cdiv(Cout, 64) * cdiv(C0 + C1, wgrad_cw(KH));
   const int nitems = B * cdiv(H, TH) * cdiv(W, TW);
   int ns = wgrad_splits(nitems, npairs);

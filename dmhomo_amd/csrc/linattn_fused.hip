@@ -1254,7 +1254,7 @@ __global__ void linattn_pack_kernel(const float* __restrict__ w, const float* __
 
 // ------------------------------------------------------------------------------------------ C ABI
 // packed image (floats): [q fragments: C*128 fp16 * 2 planes][kv fragments: C*256 fp16 * 2 planes][osc_q 128][osc_kv 256]
-extern "C" int64_t dmh_linattn_fused_pack_floats(int C) { return (int64_t)C * 128 + (int64_t)C * 256 + 128 + 256; }
+extern "C" int64_t dmh_linattn_fused_pack_floats(int C) { if (!dmh_dims_ok({C})) return -1; return (int64_t)C * 128 + (int64_t)C * 256 + 128 + 256; }
 
 extern "C" int dmh_linattn_fused_pack(const float* w_qkv, float* wpack, int C, void* stream) {
   DMH_REQUIRE(w_qkv && wpack && C > 0 && C % KC == 0, "dmh_linattn_fused_pack: C must be a multiple of 32 (got %d)", C);
@@ -1280,7 +1280,10 @@ static int fused_tiles(int B, int n) {
   return t < 1 ? 1 : (t > 8 ? 8 : t);
 }
 
-extern "C" int dmh_linattn_fused_splits(int B, int n) { return cdiv(cdiv(n, TP), fused_tiles(B, n)); }
+extern "C" int dmh_linattn_fused_splits(int B, int n) {
+  if (!dmh_dims_ok({B}) || !dmh_dims_ok({n}, 1, 1 << 26)) return -1;
+  return cdiv(cdiv(n, TP), fused_tiles(B, n));
+}
 
 // pass 1: partial[B][splits][4][LA_PART]  (then dmh_linattn_merge with the same split count)
 extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, const float* ln_g, const float* wpack,

@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(MtTable t, const float*
 }
 // blocks dmh_sumsq_multi writes partials for (the size of ``part``)
 extern "C" int64_t dmh_multi_blocks(const int64_t* n, int count) {
+  if (!n || count <= 0) return count == 0 ? 0 : -1;
   int64_t b = 0;
   for (int i = 0; i < count; ++i) b += cdiv64(n[i], MT_CHUNK);
   return b;

@@ -48,7 +48,9 @@ int dmh_version(void);
  *   elements of output channel o.  w, w_out: [Cout][K]. */
 int dmh_ws_standardize(const float* w, float* w_out, int Cout, int K, float eps, void* stream);
 
-/* number of floats of the packed image of an OIHW weight for dmh_conv2d */
+/* number of floats of the packed image of an OIHW weight for dmh_conv2d.
+ * Every pure size function of this header (dmh_*_floats, dmh_conv_tiles, dmh_*_splits, dmh_multi_blocks) answers -1 for a
+ * dimension outside (0, 2^20] (pixel counts: 2^26) or a NULL array instead of entering the size arithmetic with it. */
 int64_t dmh_conv_pack_floats(int Cout, int C0, int C1, int KH, int KW);
 
 /* OIHW [Cout][C0+C1][KH][KW] -> the image dmh_conv2d consumes (an opaque blob of dmh_conv_pack_floats floats; pack
