@@ -121,12 +121,23 @@ def run_child(cmd, timeout, env=None, cwd=None):
     return proc.returncode, out, err
 
 
+def under_profiler():
+    """True when this process runs under rocprofv3 / a rocprofiler-sdk tool preload (every process of such a tree has the GPU
+    initialised before main(): it must not start programs that exec again — shebang scripts, env, sh -c)"""
+    return 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(
+        k.startswith(('ROCPROF', 'ROCP_TOOL', 'ROCPROFILER')) for k in os.environ)
+
+
 def smi_sample(device_index):
     """ONE `rocm-smi --json` call for this rank's GPU (no sampling thread): the SMU's own running averages of clock and
     socket power, read right before and right after the timed region — on an 8-GPU chassis a throttled GPU (this workload
     sits on the power limit) shows here.  rocm-smi does not initialise HIP.  -> {field: value} or {'error': ...}"""
     import re
     import shutil
+    if under_profiler():
+        # rocm-smi is a `#!/usr/bin/env python3` script: under rocprofv3 the preloaded tool library initialises the GPU in
+        # `env` before it execs python3 — the exec-after-GPU-init this pool forbids (seen once, refused by the box, round 6)
+        return {'skipped': 'running under a profiler preload: no child programs are started'}
     exe = shutil.which('rocm-smi') or '/opt/rocm/bin/rocm-smi'
     try:
         r = subprocess.run([exe, '-d', str(device_index), '--showclocks', '--showpower', '--showtemp', '--json'],
@@ -170,7 +181,8 @@ def exact_fp32_variant(args, timeout=420):
     throughput trade of `config.arithmetic` buys on THIS box.  -> dict for the JSON line (an 'error' entry when it failed)."""
     cmd = [sys.executable, os.path.abspath(__file__), '--steps', '3', '--warmup', '1', '--bs', str(args.bs), '--s_step',
            str(args.s_step), '--image_size', str(args.image_size), '--dim', str(args.dim), '--cfg-mode', args.cfg_mode,
-           '--no-variants', '--no-traffic', '--no-cpu-baseline', '--no-roofline'] + (['--no-graph'] if args.no_graph else [])
+           '--no-variants', '--no-traffic', '--no-cpu-baseline', '--no-roofline', '--no-phases'] + (
+               ['--no-graph'] if args.no_graph else [])
     try:
         rc, out, err = run_child(cmd, timeout, env=child_env(DMH_CONV3_VARIANT='6'), cwd=ROOT)
         lines = [l for l in out.splitlines() if l.startswith('{') and '"metric"' in l]
@@ -731,7 +743,7 @@ def measure_traffic(timeout=240):
         try:
             cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', d, '-o', 't', '--',
                    sys.executable, os.path.abspath(__file__), '--steps', '1', '--warmup', '1', '--s_step', '2', '--cfg-mode',
-                   'batched', '--no-variants', '--no-cpu-baseline', '--no-roofline', '--no-graph']
+                   'batched', '--no-variants', '--no-cpu-baseline', '--no-roofline', '--no-graph', '--no-phases']
             # (rocprofv3 leads its own session: a timeout kills the profiler AND the python under it — run_child)
             rc, _, err = run_child(cmd, timeout, env=env, cwd='/tmp')
             files = glob.glob(d + '/**/*counter_collection.csv', recursive=True)

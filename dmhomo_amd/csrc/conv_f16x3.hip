@@ -145,8 +145,14 @@ __global__ __launch_bounds__(256, 2) void conv_f16x3_kernel(ConvArgs p) {
     const int total = nb * gridDim.y, lin = t + by * nb;
     const int q = total >> 3, r = total & 7, xcd = lin & 7, local = lin >> 3;
     const int nl = xcd * q + min(xcd, r) + local;
-    t = nl % nb;
-    by = nl / nb;
+    if (p.xcd == 2) {   // cout tile innermost: the output-channel tiles of one pixel tile run side by side on ONE XCD, so its
+                        // input tile is fetched into one L2 once (the <= 32^2 levels: launch_f16x3)
+      by = nl % (int)gridDim.y;
+      t = nl / (int)gridDim.y;
+    } else {
+      t = nl % nb;
+      by = nl / nb;
+    }
   }
   const int tx = t % p.tilesX;
   t /= p.tilesX;
@@ -864,6 +870,13 @@ static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
     DMH_REQUIRE(e == hipSuccess, "dmh_conv2d: cannot raise the LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
+  // development knob (round 6): DMH_CONV_XCD_DEEP=<max Hout> deals the cout tiles of one pixel tile to the SAME XCD at the levels
+  // with Hout <= that (see the kernel); a function of the layer shape only
+  static const int xcd_deep = [] {
+    const char* e = getenv("DMH_CONV_XCD_DEEP");
+    return e ? atoi(e) : 0;
+  }();
+  if (a.xcd == 1 && xcd_deep > 0 && Hout <= xcd_deep && cdiv(a.Cout, 64 * WN) > 1) a.xcd = 2;
   dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64 * WN));
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, a);
   DMH_CHECK_LAUNCH("dmh_conv2d(f16x3)");

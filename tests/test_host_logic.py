@@ -265,8 +265,15 @@ def test_bench_measurement_children_are_fresh_bounded_and_outside_the_rendezvous
     except subprocess.TimeoutExpired:
         pass
     assert time.time() - t0 < 30
-    # smi_sample never raises (no rocm-smi / no GPU here: an 'error' entry)
+    # smi_sample never raises (no rocm-smi / no GPU here: an 'error' entry) — and starts NO program under a profiler preload
+    # (rocm-smi is an env-python3 shebang script: under rocprofv3 that is an exec after GPU initialisation, which the pool forbids)
     assert isinstance(bench.smi_sample(0), dict)
+    try:
+        os.environ['ROCPROF_OUTPUT_PATH'] = '/tmp/x'
+        assert bench.under_profiler() and 'skipped' in bench.smi_sample(0)
+    finally:
+        os.environ.pop('ROCPROF_OUTPUT_PATH')
+    assert not bench.under_profiler()
 
 
 def test_training_refuses_learned_sinusoidal_models():

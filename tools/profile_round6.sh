@@ -7,17 +7,17 @@ rm -rf $O && mkdir -p $O
 stats() { find $1 -name '*kernel_stats.csv' | head -1; }
 # 1. headline line, streams / batched kernel traces, PMC traffic of the 3x3 launches
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/streams -o s -- python3 $R/bench.py --steps 2 --warmup 1 --no-variants --no-cpu-baseline --no-roofline > $O/streams.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/streams -o s -- python3 $R/bench.py --steps 2 --warmup 1 --no-variants --no-cpu-baseline --no-roofline --no-phases > $O/streams.log 2>&1
 cp "$(stats $O/streams)" $O/bench_streams_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched -o b -- python3 $R/bench.py --steps 2 --warmup 1 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline > $O/batched.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/batched -o b -- python3 $R/bench.py --steps 2 --warmup 1 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline --no-phases > $O/batched.log 2>&1
 cp "$(stats $O/batched)" $O/bench_batched_kernel_stats.csv
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --s_step 2 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline --no-graph > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --s_step 2 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline --no-graph > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 1 --warmup 1 --s_step 2 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline --no-phases --no-graph > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 1 --warmup 1 --s_step 2 --cfg-mode batched --no-variants --no-cpu-baseline --no-roofline --no-phases --no-graph > $O/pmc_write.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write 'conv_f16x3_kernel<3, 3, 1, 0' $O/pmc_traffic.json > /dev/null
 # (the same comparison bench.py prints as roofline.traffic_vs_committed: a fresh pass against the NEWEST committed figure)
 python3 $R/tools/check_traffic.py $O/pmc_traffic.json $R/profiles > $O/traffic_check.txt 2>&1; echo "traffic check exit $?" >> $O/traffic_check.txt
 # 1b. the de-duplicating step (cfg.Unet.dedup_dropped_rows) as the timed loop: kernel trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/dedup -o s -- python3 $R/bench.py --steps 2 --warmup 1 --dedup --no-variants --no-cpu-baseline --no-roofline > $O/dedup.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/dedup -o s -- python3 $R/bench.py --steps 2 --warmup 1 --dedup --no-variants --no-cpu-baseline --no-roofline --no-phases > $O/dedup.log 2>&1
 cp "$(stats $O/dedup)" $O/bench_dedup_streams_kernel_stats.csv
 if [ "$FULL" = "1" ]; then
 # 2. the README geometry (dim 64, 256x256, bs 25, s_step 32) and BASELINE configs[4] (dim 128, 256x256, bs 8, s_step 250): NOT the headline
