@@ -20,7 +20,7 @@ c_int = C.c_int
 c_float = C.c_float
 
 
-ABI_VERSION = 510          # include/dmhomo_hip.h: DMH_ABI_VERSION
+ABI_VERSION = 500          # include/dmhomo_hip.h: DMH_ABI_VERSION
 
 
 class DmhConv(C.Structure):
@@ -113,13 +113,11 @@ SIGNATURES = {
     'dmh_linattn_fused_pack_floats': (c_i64, [c_int]),
     'dmh_linattn_fused_pack': (c_int, [c_f32p, c_f32p, c_int, C.c_void_p]),
     'dmh_linattn_fused_splits': (c_int, [c_int, c_int]),
-    'dmh_linattn_fused_context': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p, c_f32p,
-                                          C.c_void_p]),
-    'dmh_linattn_pieces_floats': (c_i64, [c_int, c_int, c_int]),
+    'dmh_linattn_fused_context': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p, C.c_void_p]),
     'dmh_linattn_out_pack_floats': (c_i64, []),
     'dmh_linattn_out_pack': (c_int, [c_f32p, c_f32p, C.c_void_p]),
     'dmh_linattn_fused_apply_out': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
-                                            c_int, c_int, c_float, c_float, C.c_void_p, c_f32p, C.c_void_p]),
+                                            c_int, c_int, c_float, c_float, C.c_void_p, C.c_void_p]),
     'dmh_linattn_merge_n': (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, C.c_void_p, C.c_void_p]),
     'dmh_linattn_fused_apply': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_float,
                                         C.c_void_p, C.c_void_p]),

@@ -554,16 +554,11 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_kernel(const float* __restr
           make_float4(ctx[eb][db][0], ctx[eb][db][1], ctx[eb][db][2], ctx[eb][db][3]));
 }
 
-// xn_out (round 6, optional): the staged operand — LayerNorm(x) as two block-scaled fp16 planes — leaves the workgroup in MFMA
-// fragment order, [b][sub-tile p0 / 64][chunk 2][pixel block 4][plane 2][lane 64] x 16 B (64 B per pixel and chunk-plane: as
-// many bytes as x itself), for pass 2, whose q projection multiplies the SAME operand: wave h stores the four fragments of
-// pixel block h straight from the registers it has just read them into for its own MFMAs (one coalesced 1 KB store each).
-// Pass 2 then needs no LayerNorm, no split, no LDS staging and none of its barriers (linattn_qo_kernel<true, true>).
 __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const uint4* __restrict__ wkv,
                                                             const float* __restrict__ oscale, float* __restrict__ partial,
                                                             int n, int C, int nsplit, int tiles,
-                                                            const int32_t* __restrict__ rows, uint4* __restrict__ xn_out) {
+                                                            const int32_t* __restrict__ rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* tiles_lds = smem;  // two sets of two staging tiles, then the raw ring
   constexpr int RES = 2;            // C == 64: both chunks' weight fragments stay in registers
@@ -647,15 +642,6 @@ __global__ __launch_bounds__(256, 2) void linattn_kv_ring_kernel(const float* __
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl)
           a[mb][pl] = *reinterpret_cast<const half8*>(tile + (mb * 16 + l15) * PITCH + kg * 16 + pl * 64);
-      if (xn_out) {   // (uniform; wave h hands over pixel block h: a scalar branch per block, no exec-masked region)
-        uint4* dst = xn_out + ((((size_t)b * ((n + TP - 1) / TP) + (p0 >> 6)) * 2 + ch) * 4 + st.wave) * (2 * 64) + lane;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
-          if (mb == st.wave) {
-            dst[0] = __builtin_bit_cast(uint4, a[mb][0]);
-            dst[64] = __builtin_bit_cast(uint4, a[mb][1]);
-          }
-      }
 #define LA_TERM(pl, bexpr)                                                                          \
   _Pragma("unroll") for (int mb = 0; mb < 4; ++mb) _Pragma("unroll") for (int nb = 0; nb < 4; ++nb) \
       acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mb][pl], bexpr, acc[mb][nb], 0, 0, 0);
@@ -843,18 +829,12 @@ constexpr int YX_BYTES = 4 * TP * YP * 4;               // [head][pixel][channel
 #else
 #define DMH_QO_WAVES 2
 #endif
-// PIECES (round 6; FUSE only): the B operand of the q projection — LayerNorm(x) as fp16 pieces — arrives from pass 1 in
-// fragment order (linattn_kv_ring_kernel's xn_out: bit for bit what Stager would stage here, same expression, same static
-// scale), one coalesced 1 KB load per fragment and wave, a chunk ahead in registers: no LayerNorm, no split, no LDS tile, no
-// staging barrier in this kernel.  x itself is still read for the residual.
-template <bool FUSE, bool PIECES = false>
+template <bool FUSE>
 __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                             const float* __restrict__ g, const uint4* __restrict__ wq,
                                                             const float* __restrict__ oscale, const float* __restrict__ ctxm,
                                                             float* __restrict__ out, int n, int C, int nblk, int tiles,
-                                                            float scale, FuseOut fo, const int32_t* __restrict__ rows,
-                                                            const uint4* __restrict__ xn_in) {
-  static_assert(!PIECES || FUSE, "the hand-over exists for the fused C == 64 pass only");
+                                                            float scale, FuseOut fo, const int32_t* __restrict__ rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NBUF = FUSE ? 1 : 2;
   unsigned char* tiles_lds = smem;
@@ -942,21 +922,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
     }
   }
 
-  // PIECES: the operand fragments of one sub-tile, [chunk][pixel block * 2 + plane]; chunk c of the NEXT sub-tile is requested
-  // as soon as chunk c of this one has been multiplied
-  uint4 xq[PIECES ? 2 : 1][PIECES ? 8 : 1];
-  const int ntile = (n + TP - 1) / TP;
-  auto load_x = [&](int ch, int p0_) __attribute__((always_inline)) {
-    const uint4* src = xn_in + (((size_t)b * ntile + (p0_ >> 6)) * 2 + ch) * (8 * 64) + lane;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) xq[PIECES ? ch : 0][PIECES ? i : 0] = src[i * 64];
-  };
-  if (PIECES) {
-    if (blk * tiles * TP < n) {
-      load_x(0, blk * tiles * TP);
-      load_x(1, blk * tiles * TP);
-    }
-  } else if (blk * tiles * TP < n) {
+  if (blk * tiles * TP < n) {
     st.begin_tile(stats_b, blk * tiles * TP);
     st.issue(0);
   }
@@ -1009,20 +975,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
       }
 #undef LA_TERM
     };
-    if (PIECES) {
-      const bool more = tI + 1 < tiles && p0 + TP < n;
-#pragma unroll
-      for (int ch = 0; ch < 2; ++ch) {
-#define LA_TERM(aexpr, pl)                                                                           \
-  _Pragma("unroll") for (int db = 0; db < 2; ++db) _Pragma("unroll") for (int nbn = 0; nbn < 4; ++nbn) \
-      acc[db][nbn] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aexpr, __builtin_bit_cast(half8, xq[PIECES ? ch : 0][PIECES ? nbn * 2 + pl : 0]), acc[db][nbn], 0, 0, 0);
-        LA_TERM(__builtin_bit_cast(half8, wres[ch][db * 2]), 1)
-        LA_TERM(__builtin_bit_cast(half8, wres[ch][db * 2 + 1]), 0)
-        LA_TERM(__builtin_bit_cast(half8, wres[ch][db * 2]), 0)
-#undef LA_TERM
-        if (more) load_x(ch, p0 + TP);
-      }
-    } else if (FUSE) {  // C == 64: both chunks' q fragments stay in registers for the whole workgroup
+    if (FUSE) {  // C == 64: both chunks' q fragments stay in registers for the whole workgroup
 #pragma unroll
       for (int ch = 0; ch < 2; ++ch) chunk(ch, wres[ch]);
     } else {
@@ -1039,7 +992,7 @@ __global__ __launch_bounds__(256, DMH_QO_WAVES) void linattn_qo_kernel(const flo
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int r = 0; r < 4; ++r) qsc[db][r] = inv_s * osc[db][r] * 1.44269504088896341f;
-    if (!PIECES && tI + 1 < tiles && p0 + TP < n) {
+    if (tI + 1 < tiles && p0 + TP < n) {
       st.begin_tile(stats_b, p0 + TP);
       st.issue(0);
     }
@@ -1333,18 +1286,9 @@ extern "C" int dmh_linattn_fused_splits(int B, int n) {
 }
 
 // pass 1: partial[B][splits][4][LA_PART]  (then dmh_linattn_merge with the same split count)
-// xn_pieces (optional, C == 64 only): dmh_linattn_pieces_floats(B, n, C) floats that receive LayerNorm(x) as the staged fp16
-// pieces in fragment order, for dmh_linattn_fused_apply_out(..., xn_pieces) on the same x (see linattn_kv_ring_kernel)
-extern "C" int64_t dmh_linattn_pieces_floats(int B, int n, int C) {
-  if (!dmh_dims_ok({B, C}) || !dmh_dims_ok({n}, 1, 1 << 26)) return -1;
-  return (int64_t)B * cdiv(n, TP) * TP * C;   // per pixel: C channels x 2 planes x 2 B = C floats
-}
-
 extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, const float* ln_g, const float* wpack,
-                                         float* partial, int B, int n, int C, const int32_t* rows, float* xn_pieces,
-                                         void* stream) {
+                                         float* partial, int B, int n, int C, const int32_t* rows, void* stream) {
   DMH_REQUIRE(x && stats && ln_g && wpack && partial, "dmh_linattn_fused_context: null pointer");
-  DMH_REQUIRE(!xn_pieces || C == 2 * KC, "dmh_linattn_fused_context: the piece hand-over exists for C == 64 only (got %d)", C);
   DMH_REQUIRE(B > 0 && n > 0 && C > 0 && C % KC == 0, "dmh_linattn_fused_context: bad shape (C=%d)", C);
   const int tiles = fused_tiles(B, n), nsplit = cdiv(cdiv(n, TP), tiles);
   const uint4* wkv = reinterpret_cast<const uint4*>(wpack + (int64_t)C * 128);
@@ -1362,12 +1306,11 @@ extern "C" int dmh_linattn_fused_context(const float* x, const float* stats, con
       attr = true;
     }
     hipLaunchKernelGGL(linattn_kv_ring_kernel, dim3(B * nsplit), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wkv,
-                       osc_kv, partial, n, C, nsplit, tiles, rows, reinterpret_cast<uint4*>(xn_pieces));
-  } else if (C == 2 * KC) {
-    DMH_REQUIRE(!xn_pieces, "dmh_linattn_fused_context: the piece hand-over needs the ring kernel (DMH_LA_RING=0 is set)");
+                       osc_kv, partial, n, C, nsplit, tiles, rows);
+  } else if (C == 2 * KC)
     hipLaunchKernelGGL(linattn_kv_kernel<2>, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
                        wkv, osc_kv, partial, n, C, nsplit, tiles, rows);
-  } else
+  else
     hipLaunchKernelGGL(linattn_kv_kernel<0>, dim3(B * nsplit), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats, ln_g,
                        wkv, osc_kv, partial, n, C, nsplit, tiles, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_context");
@@ -1385,7 +1328,7 @@ extern "C" int dmh_linattn_fused_apply(const float* x, const float* stats, const
   const float* osc_q = wpack + (int64_t)C * 384;
   FuseOut fo = {};
   hipLaunchKernelGGL(linattn_qo_kernel<false>, dim3(B * nblk), dim3(256), 2 * TILE_BYTES, (hipStream_t)stream, x, stats,
-                     ln_g, wq, osc_q, ctx, out, n, C, nblk, tiles, scale, fo, rows, (const uint4*)nullptr);
+                     ln_g, wq, osc_q, ctx, out, n, C, nblk, tiles, scale, fo, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_apply");
   return DMH_OK;
 }
@@ -1443,7 +1386,7 @@ extern "C" int dmh_linattn_out_pack(const float* w_out, float* wpack, void* stre
 extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, const float* ln_g, const float* wpack,
                                            const float* ctx, const float* wopack, const float* out_bias,
                                            const float* out_ln_g, float* y, int B, int n, int C, float scale,
-                                           float eps, const int32_t* rows, const float* xn_pieces, void* stream) {
+                                           float eps, const int32_t* rows, void* stream) {
   DMH_REQUIRE(x && stats && ln_g && wpack && ctx && wopack && out_bias && out_ln_g && y,
               "dmh_linattn_fused_apply_out: null pointer");
   DMH_REQUIRE(B > 0 && n > 0 && C == 64, "dmh_linattn_fused_apply_out: only C == 64 (got %d)", C);
@@ -1464,18 +1407,12 @@ extern "C" int dmh_linattn_fused_apply_out(const float* x, const float* stats, c
 #endif
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)linattn_qo_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void*)linattn_qo_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipError_t e = hipFuncSetAttribute((const void*)linattn_qo_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     DMH_REQUIRE(e == hipSuccess, "dmh_linattn_fused_apply_out: cannot raise the LDS limit");
     attr = true;
   }
-  if (xn_pieces)   // pass 1 handed over the staged operand (dmh_linattn_fused_context(..., xn_pieces))
-    hipLaunchKernelGGL((linattn_qo_kernel<true, true>), dim3(B * nblk), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wq,
-                       osc_q, ctx, nullptr, n, C, nblk, tiles, scale, fo, rows, reinterpret_cast<const uint4*>(xn_pieces));
-  else
-    hipLaunchKernelGGL((linattn_qo_kernel<true, false>), dim3(B * nblk), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wq,
-                       osc_q, ctx, nullptr, n, C, nblk, tiles, scale, fo, rows, (const uint4*)nullptr);
+  hipLaunchKernelGGL(linattn_qo_kernel<true>, dim3(B * nblk), dim3(256), LDS, (hipStream_t)stream, x, stats, ln_g, wq,
+                     osc_q, ctx, nullptr, n, C, nblk, tiles, scale, fo, rows);
   DMH_CHECK_LAUNCH("dmh_linattn_fused_apply_out");
   return DMH_OK;
 }

@@ -281,10 +281,6 @@ class PackedLinAttnOut:
         self.ln_g = ln_g.detach().reshape(-1).contiguous().float()
 
 
-# development knob (same-box A/Bs): DMH_LA_PIECES=0 lets pass 2 of the fully fused LinearAttention stage its operand itself
-LA_PIECES = os.environ.get('DMH_LA_PIECES', '1') != '0' and os.environ.get('DMH_LA_RING', '1') != '0'
-
-
 def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None, rows=None):
     """K3f.  x (B,H,W,C) -> attention core output (B,H,W,128) of LinearAttention(PreNorm-LayerNorm(x)): LayerNorm,
     to_qkv and both attention passes in two kernels, q/k/v never stored.
@@ -300,18 +296,12 @@ def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None, 
     ns = lib().dmh_linattn_fused_splits(B, n)
     partial = _empty((B, ns, 4, 1088), x)
     ctx = _empty((B, 4, 32, 32), x)
-    # the fully fused block (C == 64): pass 1 hands its staged operand — LayerNorm(x) as fp16 pieces in fragment order — to
-    # pass 2, which then runs no LayerNorm / split / LDS staging of its own (bit for bit the same result; round 6)
-    pieces = None
-    if out is not None and LA_PIECES:
-        pieces = _empty((lib().dmh_linattn_pieces_floats(B, n, c),), x)
-    call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c, _rows(rows),
-         ptr(pieces))
+    call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c, _rows(rows))
     call('dmh_linattn_merge_n', ptr(partial), ptr(ctx), B, n, ns, _rows(rows))
     if out is not None:
         y = _empty((B, H, W, 64), x)
         call('dmh_linattn_fused_apply_out', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(out.wpack),
-             ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps), _rows(rows), ptr(pieces))
+             ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps), _rows(rows))
         return y
     o = _empty((B, H, W, 128), x)
     call('dmh_linattn_fused_apply', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(o), B, n, c,

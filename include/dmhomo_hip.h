@@ -36,7 +36,7 @@ extern "C" {
 const char* dmh_last_error(void);
 /* DMH_ABI_VERSION of the library: bumped whenever a struct layout or an entry point changes; a binding must refuse a
  * library whose version differs from the header it was written against (dmhomo_amd/_lib.py does). */
-#define DMH_ABI_VERSION 510
+#define DMH_ABI_VERSION 500
 int dmh_version(void);
 
 /* ---------------------------------------------------------------------------------------
@@ -217,12 +217,7 @@ int64_t dmh_linattn_fused_pack_floats(int C);
 int dmh_linattn_fused_pack(const float* w_qkv, float* wpack, int C, void* stream);
 int dmh_linattn_fused_splits(int B, int n);
 int dmh_linattn_fused_context(const float* x, const float* stats, const float* ln_g, const float* wpack,
-                              float* partial, int B, int n, int C, const int32_t* rows, float* xn_pieces, void* stream);
-/* xn_pieces (optional; C == 64 only; ABI 510): dmh_linattn_pieces_floats(B, n, C) floats that receive LayerNorm(x) as the two
- * block-scaled fp16 planes the projections multiply, in MFMA fragment order — pass 1 stores what it has staged, and
- * dmh_linattn_fused_apply_out(..., xn_pieces) on the SAME x loads it as its q-projection operand instead of running the
- * LayerNorm, the split and the LDS staging again (bit for bit the same result). NULL: every pass stages for itself. */
-int64_t dmh_linattn_pieces_floats(int B, int n, int C);
+                              float* partial, int B, int n, int C, const int32_t* rows, void* stream);
 int dmh_linattn_merge_n(const float* partial, float* ctx, int B, int n, int nsplit, const int32_t* rows, void* stream);
 int dmh_linattn_fused_apply(const float* x, const float* stats, const float* ln_g, const float* wpack,
                             const float* ctx, float* out, int B, int n, int C, float scale, const int32_t* rows,
@@ -234,8 +229,7 @@ int64_t dmh_linattn_out_pack_floats(void);
 int dmh_linattn_out_pack(const float* w_out, float* wpack, void* stream);
 int dmh_linattn_fused_apply_out(const float* x, const float* stats, const float* ln_g, const float* wpack,
                                 const float* ctx, const float* wopack, const float* out_bias, const float* out_ln_g,
-                                float* y, int B, int n, int C, float scale, float eps, const int32_t* rows,
-                                const float* xn_pieces, void* stream);
+                                float* y, int B, int n, int C, float scale, float eps, const int32_t* rows, void* stream);
 
 /* K4  Attention core, CFG:287-295: softmax_j((q*scale)^T k) v; out NHWC [B][n][128] */
 int dmh_attention(const float* qkv, float* out, int B, int n, float scale, const int32_t* rows, void* stream);

@@ -29,7 +29,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in header_functions():
         assert hasattr(h, name), name
     lib = _lib.lib()
-    assert lib.dmh_version() == _lib.ABI_VERSION == 510
+    assert lib.dmh_version() == _lib.ABI_VERSION == 500
 
 
 def test_pure_host_entry_points():

@@ -443,34 +443,6 @@ def test_linear_attention_block_fused_rows_independent_under_load(ops):
         assert torch.equal(ops.linear_attention_fused(x, g, pla, 32 ** -0.5)[:2], core)
 
 
-@pytest.mark.parametrize('H,W', [(128, 128), (16, 16), (7, 9), (40, 24)])
-def test_linear_attention_piece_handover_is_bitwise(ops, H, W):
-    """round 6: pass 1 of the fully fused block hands its staged operand (LayerNorm(x) as fp16 pieces, fragment order) to pass 2,
-    which then skips its own LayerNorm / split / LDS staging (dmh_linattn_fused_context / _apply_out xn_pieces): bit for bit
-    the result of the passes staging for themselves — full and ragged sub-tiles, a whole batch and a row subset"""
-    B, C = 5, 64
-    g = (1 + 0.2 * rand((C,), 51)).to(dev())
-    pla = ops.PackedLinAttn(rand((384, C, 1, 1), 52, C ** -0.5).to(dev()))
-    plo = ops.PackedLinAttnOut((rand((C, 128, 1, 1), 53, 128 ** -0.5) * 30.0).to(dev()), rand((C,), 54, 0.1).to(dev()),
-                               (1 + 0.2 * rand((C,), 55)).to(dev()))
-    x = (rand((B, H, W, C), 56) * 1.3 + 0.2).to(dev())
-    keep = torch.tensor([1, 0, 1, 1, 0], dtype=torch.uint8, device=dev())
-    rows = ops.rows_from_keep(keep)
-    was = ops.LA_PIECES
-    try:
-        ops.LA_PIECES = False
-        own = ops.linear_attention_fused(x, g, pla, 32 ** -0.5, out=plo)
-        own_rows = ops.linear_attention_fused(x, g, pla, 32 ** -0.5, out=plo, rows=rows)
-        ops.LA_PIECES = True
-        for _ in range(3):
-            assert torch.equal(ops.linear_attention_fused(x, g, pla, 32 ** -0.5, out=plo), own)
-        got_rows = ops.linear_attention_fused(x, g, pla, 32 ** -0.5, out=plo, rows=rows)
-        idx = [0, 2, 3]
-        assert torch.equal(got_rows[idx], own_rows[idx]) and torch.equal(got_rows[idx], own[idx])
-    finally:
-        ops.LA_PIECES = was
-
-
 def test_linear_attention_uniform_k_gives_mean_v(ops):
     """known answer: constant k -> softmax_n uniform -> ctx[d][e] = mean_n(v[e]) / n for every d (v is scaled by 1/n)"""
     H = W = 12

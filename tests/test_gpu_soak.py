@@ -153,7 +153,7 @@ def test_soak_ring_kernel_beside_a_conv_240_launches(ops, B):
 
     def context():
         partial = torch.zeros((B, ns, 4, 1088), device=dev())
-        call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(gq), ptr(pla.wpack), ptr(partial), B, n, C, None, None)
+        call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(gq), ptr(pla.wpack), ptr(partial), B, n, C, None)
         return partial
     torch.cuda.synchronize()
     alone = context()

@@ -19,7 +19,7 @@ ns = lib().dmh_linattn_fused_splits(B, n)
 def kv(xx, ss):
     b = xx.shape[0]
     part = torch.zeros((b, ns, 4, 1088), device=dev)
-    call('dmh_linattn_fused_context', ptr(xx), ptr(ss), ptr(g), ptr(pla.wpack), ptr(part), b, n, C, None, None)
+    call('dmh_linattn_fused_context', ptr(xx), ptr(ss), ptr(g), ptr(pla.wpack), ptr(part), b, n, C, None)
     return part
 alone = kv(x[:2].contiguous(), stats[:2].contiguous())
 w = rand((128, 128, 3, 3), 90, (1.0 / 1152) ** 0.5).to(dev)

@@ -40,7 +40,7 @@ def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None):
         real_call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, c, float(eps), None, 0)
     ns = lib().dmh_linattn_fused_splits(B, n)
     partial = _empty((B, ns, 4, 1088), x)
-    real_call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c, None, None)
+    real_call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(partial), B, n, c, None)
     key = ('merge', tuple(x.shape), pla.wpack.data_ptr(), torch.cuda.current_stream().cuda_stream)
     if 'merge' in ABLATE and key in cache:
         ctx = cache[key]
@@ -52,7 +52,7 @@ def linear_attention_fused(x, ln_g, pla, scale, eps=1e-5, out=None, stats=None):
     if out is not None:
         y = _empty((B, H, W, 64), x)
         real_call('dmh_linattn_fused_apply_out', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(out.wpack),
-                  ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps), None, None)
+                  ptr(out.bias), ptr(out.ln_g), ptr(y), B, n, c, float(scale), float(eps), None)
         return y
     o = _empty((B, H, W, 128), x)
     real_call('dmh_linattn_fused_apply', ptr(x), ptr(stats), ptr(ln_g), ptr(pla.wpack), ptr(ctx), ptr(o), B, n, c, float(scale), None)

@@ -21,7 +21,7 @@ for i in range(8):
     x = xs[i % 4]
     stats = torch.empty((B, n, 2), device=dev)
     call('dmh_pixel_stats', ptr(x), ptr(stats), B * n, C, 1e-5, None, 0)
-    call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(g), ptr(pla.wpack), ptr(part), B, n, C, None, None)
+    call('dmh_linattn_fused_context', ptr(x), ptr(stats), ptr(g), ptr(pla.wpack), ptr(part), B, n, C, None)
 torch.cuda.synchronize()
 v = part[..., :6].double().cpu()            # [B][splits][head][phase]
 tiles = (n // 64) // ns

@@ -55,12 +55,12 @@ def run(C, H, B, fuse):
     y = torch.empty((B, H, H, 64 if fuse else 128), device=dev)
 
     def p1(i):
-        call('dmh_linattn_fused_context', ptr(xs[i]), ptr(stats[i]), ptr(g), ptr(pla.wpack), ptr(partial), B, n, C, None, None)
+        call('dmh_linattn_fused_context', ptr(xs[i]), ptr(stats[i]), ptr(g), ptr(pla.wpack), ptr(partial), B, n, C, None)
 
     def p2(i):
         if fuse:
             call('dmh_linattn_fused_apply_out', ptr(xs[i]), ptr(stats[i]), ptr(g), ptr(pla.wpack), ptr(ctx), ptr(plo.wpack),
-                 ptr(plo.bias), ptr(plo.ln_g), ptr(y), B, n, C, 32 ** -0.5, 1e-5, None, None)
+                 ptr(plo.bias), ptr(plo.ln_g), ptr(y), B, n, C, 32 ** -0.5, 1e-5, None)
         else:
             call('dmh_linattn_fused_apply', ptr(xs[i]), ptr(stats[i]), ptr(g), ptr(pla.wpack), ptr(ctx), ptr(y), B, n, C,
                  32 ** -0.5, None)
