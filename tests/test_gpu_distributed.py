@@ -44,6 +44,18 @@ for k in grads:
 t = torch.tensor([1.5, 2.5], device=dev, dtype=torch.float64)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)       # the timing reduction of bench.py
 assert t.tolist() == [1.5, 2.5]
+# the per-rank / per-phase diagnosis of an N-rank bench line travels as one all_gather_object (bench.assemble_phases): the
+# object path of torch.distributed over RCCL (pickle -> byte tensors on the current device -> all_gather) on this stack
+import importlib.util
+spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(os.environ['DMH_ROOT'], 'bench.py'))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+mine = {'rank': 0, 'ms_per_step': 280.5, 'local_ms': 279.0, 'gather_ms': 0.4, 'smi_before': bench.smi_sample(0),
+        'smi_after': {'sclk clock speed': 2000.0}, 'host': 'h', 'device': 'cuda:0'}
+got = [None]
+dist.all_gather_object(got, mine)
+assert got[0] == mine and isinstance(mine['smi_before'], dict) and 'error' not in mine['smi_before'], mine['smi_before']
+ph = bench.assemble_phases(mine, 0, 1, 3.0, 30.0)
+assert ph['per_rank_ms'] == [280.5] and ph['straggler_rank'] == 0 and ph['smi'][0]['before'] == mine['smi_before']
 dist.barrier()
 torch.cuda.synchronize()
 dist.destroy_process_group()
