@@ -870,13 +870,21 @@ static int launch_f16x3(const DmhConv* d, int Hout, int Wout, hipStream_t st) {
     DMH_REQUIRE(e == hipSuccess, "dmh_conv2d: cannot raise the LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  // development knob (round 6): DMH_CONV_XCD_DEEP=<max Hout> deals the cout tiles of one pixel tile to the SAME XCD at the levels
-  // with Hout <= that (see the kernel); a function of the layer shape only
+  // round 6: at the levels with Hout <= 32 the cout tiles of one pixel tile are dealt to the SAME XCD (a.xcd = 2: the re-deal
+  // walks the cout tile innermost; a function of the layer shape only, results bitwise unchanged).  Measured with a tight
+  // A/B (10 alternating rounds, standard error 0.05 %): +0.24 % / +0.29 % / +0.29 % images/s on three boxes, all of it from
+  // the launches with four cout tiles (512-wide @16^2: one under-filled round of workgroups, where every XCD now fetches its
+  // input tiles once instead of four XCDs each), although their FETCH_SIZE goes UP (weights re-streamed per XCD: from the
+  // Infinity Cache); docs/EXPERIMENTS.md R6.1.  DMH_CONV_XCD_DEEP=0 restores the order of rounds 1-5 (cout tile outermost).
   static const int xcd_deep = [] {
     const char* e = getenv("DMH_CONV_XCD_DEEP");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 32;
   }();
-  if (a.xcd == 1 && xcd_deep > 0 && Hout <= xcd_deep && cdiv(a.Cout, 64 * WN) > 1) a.xcd = 2;
+  static const int xcd_deep_maxy = [] {   // (development knob: only launches with at most this many cout tiles)
+    const char* e = getenv("DMH_CONV_XCD_DEEP_MAXY");
+    return e ? atoi(e) : 1 << 20;
+  }();
+  if (a.xcd == 1 && xcd_deep > 0 && Hout <= xcd_deep && cdiv(a.Cout, 64 * WN) > 1 && cdiv(a.Cout, 64 * WN) <= xcd_deep_maxy) a.xcd = 2;
   dim3 grid(a.tilesX * a.tilesY * a.B, cdiv(a.Cout, 64 * WN));
   hipLaunchKernelGGL(kern, grid, dim3(256), Cfg::LDS_BYTES, st, a);
   DMH_CHECK_LAUNCH("dmh_conv2d(f16x3)");
