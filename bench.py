@@ -827,11 +827,14 @@ def roofline(log, args):
         'traffic_committed': committed,
         'traffic_vs_committed': (traffic / committed) if (traffic and committed) else None,
         'algorithmic_bytes_per_launch_avg': by3 / max(n3, 1),
-        'traffic_vs_algorithmic_note': 'the canonical launch alone moves 1.02x its algorithmic bytes (profiles/r05_pmc_canonical.json); '
-                                       'the average over ALL stride-1 3x3 launches sits ~1.2x above the SURVEY 8d sum because the <= 32^2 '
-                                       'levels fetch their (small) input once per 128-channel output tile — those tiles run on different '
-                                       'XCDs, i.e. behind different L2s, so that each XCD keeps its weight slice resident (512->512@16^2: 130 MB '
-                                       'fetched for 36 MB of algorithmic reads, at < 1 TB/s: those launches are latency-bound, DESIGN 3.1)',
+        'traffic_vs_algorithmic_note': 'the canonical launch alone moves 1.02x its algorithmic bytes (profiles/r05_pmc_canonical.json); the '
+                                       'average over ALL stride-1 3x3 launches sits ~1.24x above the SURVEY 8d sum because of the <= 32^2 levels. '
+                                       'Since round 6 the cout tiles of one pixel tile run on the SAME XCD there (DMH_CONV_XCD_DEEP=32): a launch '
+                                       'fetches its input once per XCD instead of once per cout tile, and every XCD streams the whole weight image '
+                                       '(9.4 MB at 512->512@16^2 through a 4 MB L2: re-fetched from the Infinity Cache) — FETCH_SIZE of those '
+                                       'launches went UP by a third, of 256->256@32^2 down by a quarter, +2 % on this average, and the step got '
+                                       '0.24-0.29 % FASTER (tight A/B on three boxes, profiles/r06_ab_xcd.txt): these launches move < 1 TB/s, '
+                                       'their bytes cost no time (DESIGN 3.1); DMH_CONV_XCD_DEEP=0 restores 242 MB',
         'measured_in': 'one extra untimed step, cfg_mode=batched, HIP events on the launch stream',
         'launches': int(n3), 'avg_launch_us': ms3 / max(n3, 1) * 1e3,
         'algorithmic_flop_per_launch': fl3 / max(n3, 1),
